@@ -1,0 +1,218 @@
+/* libpeppa_hip.so -- C ABI of the MI355X (gfx950) hot path of the PeppaPig training step.
+ *
+ * The reference (gchrupala/peppa) has no FFI: its boundary is the Python API of
+ * pig/models.py, pig/loss.py, pig/optimization.py.  Each entry point below
+ * names the reference call it replaces (file:line under the reference tree).  The library
+ *   - borrows raw device pointers for the duration of the call (PyTorch owns all memory),
+ *   - only enqueues work on the given hipStream_t, never synchronises, never allocates,
+ *   - returns 0 or a negative pp_status; pp_last_error() gives the message (thread-local).
+ * Activations are bf16 (raw uint16 bits), channels-last, channel stride padded to a multiple
+ * of 16; statistics, norms, loss and optimizer state are fp32.
+ */
+#ifndef PEPPA_HIP_H
+#define PEPPA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pp_stream_t; /* hipStream_t */
+enum pp_status { PP_OK = 0, PP_ERR_INVALID = -1, PP_ERR_UNSUPPORTED = -2, PP_ERR_HIP = -3 };
+enum pp_act { PP_ACT_NONE = 0, PP_ACT_GELU = 1, PP_ACT_RELU = 2 };
+enum pp_gather_mode { PP_DENSE = 0, PP_CONV_FWD = 1, PP_CONV_DGRAD = 2 };
+
+int pp_version(void);
+const char* pp_last_error(void);
+
+/* Row gather shared by pp_igemm / pp_wgrad: how logical row m and reduce index k of the
+ * left operand map to memory.
+ *   PP_DENSE      : A[m*lda + k].
+ *   PP_CONV_FWD   : m -> (n, rt, rh, rw) over (Rt,Rh,Rw); k -> (tap, c), tap -> (dt,dh,dw);
+ *                   source position g = r*stride - pad + d inside (Gt,Gh,Gw), else zero.
+ *   PP_CONV_DGRAD : source position g = (r + pad - d)/stride when divisible and in range.
+ * The source tensor is channels-last [n][Gt][Gh][Gw][cstride] (bf16); `cg` channels are
+ * read per tap (multiple of 8).  1-D convolutions use Gh=Gw=Rh=Rw=1.
+ * Replaces torch.nn.Conv3d / Conv1d / Linear inside torchvision r2plus1d_18 and torchaudio
+ * wav2vec2_base as called from pig/models.py:141-150 and pig/models.py:101-105. */
+typedef struct pp_gather {
+  int mode;
+  int lda;                /* PP_DENSE: row stride in elements */
+  int Rt, Rh, Rw;         /* row decomposition extents */
+  int Gt, Gh, Gw;         /* source tensor extents */
+  int kt, kh, kw;         /* taps */
+  int st, sh, sw;         /* strides (dgrad: 1 or 2) */
+  int pt, ph, pw;         /* paddings */
+  int cg;                 /* channels per tap */
+  int cstride;            /* channel stride of the source tensor */
+} pp_gather;
+
+/* C[M,N] = act(A_gather[M,K] * Bt[N,K]^T + bias) (+ residual).  bf16 in, fp32 accumulate.
+ * grid.z runs `nbatch` independent problems; batch z uses offsets
+ * (z / inner) * stride0 + (z % inner) * stride1 on A, Bt, C, bias (elements). */
+typedef struct pp_igemm_desc {
+  int M, N, K;
+  pp_gather g;
+  const void* A;
+  const void* Bt; int ldb; int b_rows;   /* Bt is [b_rows][ldb], rows >= b_rows read as 0 */
+  void* C; int ldc; int c_fp32;          /* bf16 (default) or fp32 output */
+  void* Cpre;                            /* optional: pre-activation copy (bf16, ldc) */
+  const float* bias;                     /* optional [N] */
+  int act;
+  const void* residual; int ldr;         /* optional bf16 [M][ldr], added after act */
+  float* colstats; int ldstat;           /* optional [ceil(M/128)][2][ldstat] partial col sums */
+  int nbatch, inner;
+  long long a_s0, a_s1, b_s0, b_s1, c_s0, c_s1, bias_s0, bias_s1;
+} pp_igemm_desc;
+int pp_igemm(const pp_igemm_desc* d, pp_stream_t s);
+
+/* dW[Ni,Kj] += sum_m dY[m,Ni]^T * X_gather[m,Kj]  (weight gradients; fp32 atomics).
+ * Replaces autograd's conv/linear weight-gradient for the same modules. dW must be zeroed. */
+typedef struct pp_wgrad_desc {
+  int M, Ni, Kj;
+  pp_gather g;                    /* gather of X (same geometry as the forward) */
+  const void* X;
+  const void* dY; int ldy;
+  float* dW; int ldw;
+  int msplit;                     /* 0 = choose automatically */
+  int nbatch;                     /* grouped conv: groups */
+  long long x_s, dy_s, dw_s;      /* per-batch offsets (elements) */
+} pp_wgrad_desc;
+int pp_wgrad(const pp_wgrad_desc* d, pp_stream_t s);
+
+/* ---- weight preparation (fp32 master -> bf16 operand layouts) and gradient un-preparation */
+/* w [Co][Ci][taps] fp32 -> out [rows_out][taps][cg] bf16 (zero padded), optional tap flip.
+ * transpose_io=1 builds the dgrad operand [Ci][taps(flipped)][cog]. */
+int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, void* out, int rows_out, int cg,
+                        int transpose_io, int flip, float scale, pp_stream_t s);
+/* g [Co][taps][cg] fp32 (pp_wgrad layout) -> dw [Co][Ci][taps] fp32, dw = g (beta=0) or += */
+int pp_unprep_conv_grad(const float* g, int Co, int Ci, int taps, int cg, float* dw, pp_stream_t s);
+/* generic 2-D fp32 -> bf16 copy with padding / transpose: out[r][c] = in[r][c] (or in[c][r]) */
+int pp_cast_pad_2d(const float* in, int rows, int cols, int ld_in, void* out, int rows_out, int ld_out,
+                   int transpose, pp_stream_t s);
+int pp_cast_f32_to_bf16(const float* in, void* out, long long n, pp_stream_t s);
+int pp_cast_bf16_to_f32(const void* in, float* out, long long n, pp_stream_t s);
+/* strided fp32 2-D copy: out[r*ld_out + c] = in[r*ld_in + c] */
+int pp_copy_2d_f32(const float* in, int ld_in, float* out, int ld_out, int rows, int cols, pp_stream_t s);
+/* batched bf16 transpose: in [nb][R][ld_in] (cols C) -> out [nb][C][ld_out] (cols R, zero padded) */
+int pp_transpose_bf16(const void* in, long long in_bs, int ld_in, void* out, long long out_bs, int ld_out,
+                      int nb, int R, int C, int inner, long long in_s1, long long out_s1, pp_stream_t s);
+int pp_fill_f32(float* p, float v, long long n, pp_stream_t s);
+
+/* ---- video input transform: pig/models.py:327-342 build_transform + layout change ------
+ * x fp32 [B][3][T][H][W] in [0,1] -> out bf16 [B][T][H][W][8], (x-mean)/std, channels 3..7 = 0 */
+int pp_video_normalize_ndhwc(const float* x, void* out, int B, int T, int H, int W,
+                             const float* mean3 /* HOST */, const float* std3 /* HOST */, pp_stream_t s);
+
+/* ---- BatchNorm3d (train mode) : torchvision BN layers inside R3DEncoder ---------------- */
+/* reduce igemm colstats partials -> mean, rstd, scale=gamma*rstd, shift=beta-mean*scale;
+ * updates running stats (momentum, unbiased var). C real channels, Cp padded (scale/shift=0). */
+int pp_bn_finalize(const float* partials, int nblk, int ldstat, long long count, int C, int Cp,
+                   const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
+                   float* shift, pp_stream_t s);
+/* stats straight from a bf16 tensor [M][Cp] (used when no igemm epilogue produced them) */
+int pp_colstats_bf16(const void* y, long long M, int Cp, float* partials, int nblk, pp_stream_t s);
+/* z = relu?(y*scale+shift (+res)) */
+int pp_bn_apply(const void* y, const float* scale, const float* shift, const void* res, int relu, void* z,
+                long long M, int Cp, pp_stream_t s);
+/* backward: pass 1 partial sums of dzm and dzm*xhat (dzm = dz masked by z>0 when relu) */
+int pp_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
+                     int relu, float* partials, int nblk, long long M, int Cp, pp_stream_t s);
+/* pass 2: sums -> dgamma,dbeta (C real channels), coefficient vectors for the apply pass */
+int pp_bn_bwd_finalize(const float* partials, int nblk, long long count, int C, int Cp, const float* gamma,
+                       const float* rstd, float* dgamma, float* dbeta, float* coef, pp_stream_t s);
+/* pass 3: dy = gamma*rstd*(dzm - mean(dzm) - xhat*mean(dzm*xhat)); optional dres = dzm */
+int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
+                    const float* coef, int relu, void* dy, void* dres, long long M, int Cp, pp_stream_t s);
+
+/* ---- elementwise on bf16 [n] ------------------------------------------------------------ */
+int pp_gelu_fwd(const void* x, void* y, long long n, pp_stream_t s);
+int pp_gelu_bwd(const void* dy, const void* x, void* dx, long long n, pp_stream_t s);
+int pp_add_bf16(const void* a, const void* b, void* out, long long n, pp_stream_t s);
+/* per-column sums of a bf16 matrix [M][ld] -> fp32 out[N] (bias gradients); out is overwritten */
+int pp_colsum_bf16(const void* x, long long M, int N, int ld, float* out, pp_stream_t s);
+
+/* ---- LayerNorm over the last dim (torchaudio wav2vec2 components) ---------------------- */
+int pp_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
+                     float* rstd, int rows, int D, pp_stream_t s);
+/* dgamma/dbeta are accumulated (+=) with atomics; zero them first */
+int pp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                     void* dx, float* dgamma, float* dbeta, int rows, int D, pp_stream_t s);
+
+/* ---- softmax over attention scores (SelfAttention in wav2vec2) ------------------------- */
+/* S fp32 [nb][T][lds] -> P bf16 [nb][T][ldp], P = softmax(scale*S) over T cols, pad cols = 0 */
+int pp_softmax_fwd(const float* S, int lds, void* P, int ldp, int nb, int T, float scale, pp_stream_t s);
+/* dS bf16 [nb][T][ldp] = scale * P * (dP - sum_j P*dP); dP fp32 [nb][T][lds] */
+int pp_softmax_bwd(const float* dP, int lds, const void* P, int ldp, void* dS, int nb, int T, float scale,
+                   pp_stream_t s);
+
+/* ---- wav2vec2 feature extractor layer 0: Conv1d(1,512,10,5) + GroupNorm(512,512) + GELU  */
+/* pass 1: per-(b,c) sum / sumsq of the conv output over time -> stats [B][512][2] (zeroed) */
+int pp_conv0_stats(const float* wave, int B, int L, int T0, const float* w, float* stats, pp_stream_t s);
+/* pass 2: recompute conv, normalise, affine, GELU -> out bf16 [B][T0][512] */
+int pp_conv0_apply(const float* wave, int B, int L, int T0, const float* w, const float* stats,
+                   const float* gamma, const float* beta, float eps, void* out, pp_stream_t s);
+/* backward: dout bf16 [B][T0][512] -> dw [512][10], dgamma, dbeta (all accumulated, zero first).
+ * red [B][512][2] scratch (zeroed). */
+int pp_conv0_bwd_reduce(const float* wave, int B, int L, int T0, const float* w, const float* stats,
+                        const float* gamma, const float* beta, float eps, const void* dout, float* red,
+                        pp_stream_t s);
+int pp_conv0_bwd_apply(const float* wave, int B, int L, int T0, const float* w, const float* stats,
+                       const float* gamma, const float* beta, float eps, const void* dout, const float* red,
+                       float* dw, float* dgamma, float* dbeta, pp_stream_t s);
+
+/* ---- positional conv weight-norm (dim=2): w = g * v / ||v||_{(0,1)} --------------------- */
+/* v [768][48][128], g [128] -> norm [128], out bf16 operand [768][128][48] (pp_igemm layout) */
+int pp_weightnorm_fwd(const float* v, const float* g, int Co, int Ci, int Kk, float* norm, void* out,
+                      pp_stream_t s);
+/* dwt fp32 [Co][Kk][Ci] (pp_wgrad layout) -> dv [Co][Ci][Kk], dg [Kk] */
+int pp_weightnorm_bwd(const float* dwt, const float* v, const float* g, const float* norm, int Co, int Ci,
+                      int Kk, float* dv, float* dg, float* dot_ws /* [Kk] scratch */, pp_stream_t s);
+
+/* ---- pooling heads: pig/models.py:30-43 Attention, :213-221 VideoAttention -------------- */
+/* spatial mean: x bf16 [B][T][HW][Cp] -> out fp32 [B][T][C] */
+int pp_spatial_mean_fwd(const void* x, float* out, int B, int T, int HW, int C, int Cp, pp_stream_t s);
+int pp_spatial_mean_bwd(const float* dout, void* dx, int B, int T, int HW, int C, int Cp, pp_stream_t s);
+/* attention pooling over time + Linear projection + L2 normalise (F.normalize eps 1e-12):
+ * x fp32 [B][T][F]; W1 [Hd][F], b1 [Hd], W2 [F][Hd], b2 [F], Wp [E][F], bp [E] (Wp may be NULL)
+ * saves alpha [B][T][F], hid [B][T][Hd], pooled [B][F], pre [B][E], out [B][E] */
+int pp_attnpool_fwd(const float* x, int B, int T, int F, int Hd, int E, const float* W1, const float* b1,
+                    const float* W2, const float* b2, const float* Wp, const float* bp, float* hid,
+                    float* alpha, float* pooled, float* pre, float* out, pp_stream_t s);
+/* dW1..dbp and dx [B][T][F] are overwritten */
+int pp_attnpool_bwd(const float* dout, const float* x, int B, int T, int F, int Hd, int E, const float* W1,
+                    const float* W2, const float* Wp, const float* hid, const float* alpha,
+                    const float* pooled, const float* pre, const float* out, float* dx, float* dW1,
+                    float* db1, float* dW2, float* db2, float* dWp, float* dbp,
+                    float* ws /* pp_attnpool_ws_floats() floats */, pp_stream_t s);
+size_t pp_attnpool_ws_floats(int B, int T, int F, int Hd, int E);
+
+/* ---- pig/loss.py:33-55 TripletLoss = contrastive(cosine_matrix(V, A), margin) ---------- */
+size_t pp_triplet_workspace_bytes(int N, int D);
+/* V, A fp32 [N][D] (rows >= n_valid must not exist); loss[0] overwritten; ws keeps the state
+ * pp_triplet_loss_bwd needs. */
+int pp_triplet_loss_fwd(const float* V, const float* A, int N, int D, float margin, float* loss, void* ws,
+                        size_t ws_bytes, pp_stream_t s);
+/* dV, dA fp32 [N][D] = dloss * dL/dV, dL/dA (dloss read from device memory) */
+int pp_triplet_loss_bwd(const float* V, const float* A, int N, int D, const float* dloss, const void* ws,
+                        float* dV, float* dA, pp_stream_t s);
+
+/* ---- pig/optimization.py:101-179 BertAdam.step (multi-tensor) --------------------------- */
+typedef struct pp_tensor_list {
+  int n_tensors;
+  float* const* p;
+  const float* const* g;
+  float* const* m;
+  float* const* v;
+  const long long* numel;
+} pp_tensor_list; /* the pointer arrays live in DEVICE memory */
+/* chunk table (device): chunk c covers tensor chunk_tensor[c], elements [chunk_off[c], +chunk) */
+int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off,
+                     int n_chunks, int chunk, float* norms /* [n_tensors] scratch */, float lr_scheduled,
+                     float b1, float b2, float eps, float weight_decay, float max_grad_norm, pp_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+"""ctypes binding of libpeppa_hip.so (C ABI declared in include/peppa_hip.h).
+
+The library is the product's only compute path: there is no CPU or PyTorch fallback.
+`lib()` raises `PeppaHipError` when the shared object is missing or a call fails.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpeppa_hip.so")
+
+
+class PeppaHipError(RuntimeError):
+    pass
+
+
+class Gather(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "mode", "lda", "Rt", "Rh", "Rw", "Gt", "Gh", "Gw", "kt", "kh", "kw",
+        "st", "sh", "sw", "pt", "ph", "pw", "cg", "cstride")]
+
+
+class IGemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("g", Gather),
+        ("A", C.c_void_p), ("Bt", C.c_void_p), ("ldb", C.c_int), ("b_rows", C.c_int),
+        ("C", C.c_void_p), ("ldc", C.c_int), ("c_fp32", C.c_int), ("Cpre", C.c_void_p),
+        ("bias", C.c_void_p), ("act", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int),
+        ("colstats", C.c_void_p), ("ldstat", C.c_int), ("nbatch", C.c_int), ("inner", C.c_int),
+        ("a_s0", C.c_longlong), ("a_s1", C.c_longlong), ("b_s0", C.c_longlong), ("b_s1", C.c_longlong),
+        ("c_s0", C.c_longlong), ("c_s1", C.c_longlong), ("bias_s0", C.c_longlong), ("bias_s1", C.c_longlong)]
+
+
+class WGradDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("Ni", C.c_int), ("Kj", C.c_int), ("g", Gather),
+        ("X", C.c_void_p), ("dY", C.c_void_p), ("ldy", C.c_int), ("dW", C.c_void_p), ("ldw", C.c_int),
+        ("msplit", C.c_int), ("nbatch", C.c_int),
+        ("x_s", C.c_longlong), ("dy_s", C.c_longlong), ("dw_s", C.c_longlong)]
+
+
+class TensorList(C.Structure):
+    _fields_ = [("n_tensors", C.c_int), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p),
+                ("v", C.c_void_p), ("numel", C.c_void_p)]
+
+
+P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+# name -> argtypes (everything returns int status unless listed in _RESTYPE)
+SIGNATURES = {
+    "pp_version": [],
+    "pp_last_error": [],
+    "pp_igemm": [C.POINTER(IGemmDesc), P],
+    "pp_wgrad": [C.POINTER(WGradDesc), P],
+    "pp_prep_conv_weight": [P, I, I, I, P, I, I, I, I, F, P],
+    "pp_unprep_conv_grad": [P, I, I, I, I, P, P],
+    "pp_cast_pad_2d": [P, I, I, I, P, I, I, I, P],
+    "pp_cast_f32_to_bf16": [P, P, L, P],
+    "pp_cast_bf16_to_f32": [P, P, L, P],
+    "pp_copy_2d_f32": [P, I, P, I, I, I, P],
+    "pp_transpose_bf16": [P, L, I, P, L, I, I, I, I, I, L, L, P],
+    "pp_fill_f32": [P, F, L, P],
+    "pp_video_normalize_ndhwc": [P, P, I, I, I, I, C.POINTER(F), C.POINTER(F), P],
+    "pp_bn_finalize": [P, I, I, L, I, I, P, P, F, F, P, P, P, P, P, P, P],
+    "pp_colstats_bf16": [P, L, I, P, I, P],
+    "pp_bn_apply": [P, P, P, P, I, P, L, I, P],
+    "pp_bn_bwd_reduce": [P, P, P, P, P, I, P, I, L, I, P],
+    "pp_bn_bwd_finalize": [P, I, L, I, I, P, P, P, P, P, P],
+    "pp_bn_bwd_apply": [P, P, P, P, P, P, I, P, P, L, I, P],
+    "pp_gelu_fwd": [P, P, L, P],
+    "pp_gelu_bwd": [P, P, P, L, P],
+    "pp_add_bf16": [P, P, P, L, P],
+    "pp_colsum_bf16": [P, L, I, I, P, P],
+    "pp_layernorm_fwd": [P, P, P, F, P, P, P, I, I, P],
+    "pp_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, P],
+    "pp_softmax_fwd": [P, I, P, I, I, I, F, P],
+    "pp_softmax_bwd": [P, I, P, I, P, I, I, F, P],
+    "pp_conv0_stats": [P, I, I, I, P, P, P],
+    "pp_conv0_apply": [P, I, I, I, P, P, P, P, F, P, P],
+    "pp_conv0_bwd_reduce": [P, I, I, I, P, P, P, P, F, P, P, P],
+    "pp_conv0_bwd_apply": [P, I, I, I, P, P, P, P, F, P, P, P, P, P, P],
+    "pp_weightnorm_fwd": [P, P, I, I, I, P, P, P],
+    "pp_weightnorm_bwd": [P, P, P, P, I, I, I, P, P, P, P],
+    "pp_spatial_mean_fwd": [P, P, I, I, I, I, I, P],
+    "pp_spatial_mean_bwd": [P, P, I, I, I, I, I, P],
+    "pp_attnpool_fwd": [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    "pp_attnpool_bwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "pp_attnpool_ws_floats": [I, I, I, I, I],
+    "pp_triplet_workspace_bytes": [I, I],
+    "pp_triplet_loss_fwd": [P, P, I, I, F, P, P, Z, P],
+    "pp_triplet_loss_bwd": [P, P, I, I, P, P, P, P, P],
+    "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P],
+}
+_RESTYPE = {"pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z}
+_NO_STATUS = set(_RESTYPE) | {"pp_version"}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; fail loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PeppaHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). peppa_amd has no CPU/PyTorch fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the header and the .so disagree
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        _lib = h
+    return _lib
+
+
+def call(name, *args):
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if name not in _NO_STATUS and rc != 0:
+        raise PeppaHipError(f"{name} failed ({rc}): {h.pp_last_error().decode()}")
+    return rc

@@ -1,0 +1,261 @@
+// Train-mode BatchNorm3d on channels-last bf16 activations [M rows][Cp channels] (gfx950).
+// HBM-bound streaming kernels: 16-byte (8-channel) accesses, per-channel partial sums kept
+// deterministic (per-block slabs + a finalize pass, no float atomics).
+// Replaces the 37 torch.nn.BatchNorm3d layers of torchvision r2plus1d_18 (pig/models.py:141-150).
+#include "common.h"
+
+namespace {
+
+// Column-partial reducer: block b handles rows [b*rows_per_blk, ...); thread owns one 8-channel
+// chunk and strides over rows; NACC running sums per channel.
+template <int NACC, class F>
+__device__ __forceinline__ void col_reduce(long long M, int Cp, int rows_per_blk, float* partials, F f) {
+  extern __shared__ float red[];
+  const int cpr = Cp >> 3;               // chunks per row
+  const int rpb = 256 / cpr;             // rows processed concurrently
+  const int tid = threadIdx.x;
+  const int ch = tid % cpr, rsub = tid / cpr;
+  const long long r0 = (long long)blockIdx.x * rows_per_blk;
+  long long r1 = r0 + rows_per_blk;
+  if (r1 > M) r1 = M;
+  float acc[NACC][8];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[a][q] = 0.f;
+  if (rsub < rpb)
+    for (long long r = r0 + rsub; r < r1; r += rpb) f(r, ch, acc);
+  // reduce across rsub through LDS: red[rsub][NACC][Cp]
+  if (rsub < rpb) {
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) red[(rsub * NACC + a) * Cp + ch * 8 + q] = acc[a][q];
+  }
+  __syncthreads();
+  for (int i = tid; i < NACC * Cp; i += 256) {
+    float s = 0.f;
+    for (int r = 0; r < rpb; ++r) s += red[r * NACC * Cp + i];
+    partials[(long long)blockIdx.x * NACC * Cp + i] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void colstats_kernel(const bfraw* __restrict__ y, long long M, int Cp,
+                                                       int rows_per_blk, float* partials) {
+  col_reduce<2>(M, Cp, rows_per_blk, partials, [&](long long r, int ch, float (*acc)[8]) {
+    const uint4 v = *(const uint4*)(y + r * Cp + ch * 8);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { acc[0][q] += f[q]; acc[1][q] += f[q] * f[q]; }
+  });
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int ldstat,
+                                                          double count, int C, int Cp, const float* gamma,
+                                                          const float* beta, float eps, float momentum,
+                                                          float* running_mean, float* running_var, float* mean,
+                                                          float* rstd, float* scale, float* shift) {
+  __shared__ double s1s[16][17], s2s[16][17];
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < ldstat)
+    for (int b = part; b < nblk; b += 16) {
+      s1 += partials[((long long)b * 2 + 0) * ldstat + c];
+      s2 += partials[((long long)b * 2 + 1) * ldstat + c];
+    }
+  s1s[part][cl] = s1;
+  s2s[part][cl] = s2;
+  __syncthreads();
+  if (part == 0 && c < Cp) {
+    for (int q = 1; q < 16; ++q) { s1 += s1s[q][cl]; s2 += s2s[q][cl]; }
+    if (c < C) {
+      const double mu = s1 / count;
+      double var = s2 / count - mu * mu;
+      if (var < 0.0) var = 0.0;
+      const float rs = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = gamma[c] * rs;
+      mean[c] = (float)mu;
+      rstd[c] = rs;
+      scale[c] = sc;
+      shift[c] = beta[c] - (float)mu * sc;
+      if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      }
+    } else {
+      mean[c] = 0.f; rstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bfraw* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const bfraw* __restrict__ res,
+                                                       int relu, bfraw* __restrict__ z, long long nchunks, int cpr) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cpr) * 8;
+    float f[8], r[8];
+    unpack8(*(const uint4*)(y + i * 8), f);
+    const float4 s0 = *(const float4*)(scale + c), s1 = *(const float4*)(scale + c + 4);
+    const float4 h0 = *(const float4*)(shift + c), h1 = *(const float4*)(shift + c + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    if (res) unpack8(*(const uint4*)(res + i * 8), r);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = f[q] * sc[q] + sh[q];
+      if (res) v += r[q];
+      if (relu) v = fmaxf(v, 0.f);
+      f[q] = v;
+    }
+    *(uint4*)(z + i * 8) = pack8(f);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bfraw* __restrict__ dz, const bfraw* __restrict__ y,
+                                                            const bfraw* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int relu, long long M, int Cp,
+                                                            int rows_per_blk, float* partials) {
+  col_reduce<2>(M, Cp, rows_per_blk, partials, [&](long long r, int ch, float (*acc)[8]) {
+    const long long o = r * Cp + ch * 8;
+    float d[8], yy[8], zz[8];
+    unpack8(*(const uint4*)(dz + o), d);
+    unpack8(*(const uint4*)(y + o), yy);
+    if (relu) unpack8(*(const uint4*)(z + o), zz);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = ch * 8 + q;
+      const float g = (relu && !(zz[q] > 0.f)) ? 0.f : d[q];
+      const float xh = (yy[q] - mean[c]) * rstd[c];
+      acc[0][q] += g;
+      acc[1][q] += g * xh;
+    }
+  });
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, double count,
+                                                              int C, int Cp, const float* gamma, const float* rstd,
+                                                              float* dgamma, float* dbeta, float* coef) {
+  __shared__ double s1s[16][17], s2s[16][17];
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < Cp)
+    for (int b = part; b < nblk; b += 16) {
+      s1 += partials[((long long)b * 2 + 0) * Cp + c];
+      s2 += partials[((long long)b * 2 + 1) * Cp + c];
+    }
+  s1s[part][cl] = s1;
+  s2s[part][cl] = s2;
+  __syncthreads();
+  if (part == 0 && c < Cp) {
+    for (int q = 1; q < 16; ++q) { s1 += s1s[q][cl]; s2 += s2s[q][cl]; }
+    if (c < C) {
+      dbeta[c] = (float)s1;
+      dgamma[c] = (float)s2;
+      coef[c] = gamma[c] * rstd[c];
+      coef[Cp + c] = (float)(s1 / count);
+      coef[2 * Cp + c] = (float)(s2 / count);
+    } else {
+      coef[c] = 0.f; coef[Cp + c] = 0.f; coef[2 * Cp + c] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bfraw* __restrict__ dz, const bfraw* __restrict__ y,
+                                                           const bfraw* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ coef,
+                                                           int relu, bfraw* __restrict__ dy, bfraw* __restrict__ dres,
+                                                           long long nchunks, int cpr, int Cp) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
+    const int c0 = (int)(i % cpr) * 8;
+    float d[8], yy[8], zz[8], o[8];
+    unpack8(*(const uint4*)(dz + i * 8), d);
+    unpack8(*(const uint4*)(y + i * 8), yy);
+    if (relu) unpack8(*(const uint4*)(z + i * 8), zz);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + q;
+      const float g = (relu && !(zz[q] > 0.f)) ? 0.f : d[q];
+      const float xh = (yy[q] - mean[c]) * rstd[c];
+      o[q] = coef[c] * (g - coef[Cp + c] - xh * coef[2 * Cp + c]);
+      d[q] = g;
+    }
+    *(uint4*)(dy + i * 8) = pack8(o);
+    if (dres) *(uint4*)(dres + i * 8) = pack8(d);
+  }
+}
+
+int stream_grid(long long nchunks) {
+  long long b = (nchunks + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define CHECK_CP(Cp, who) PP_CHECK_ARG((Cp) > 0 && (Cp) % 8 == 0 && (Cp) <= 2048, who ": Cp=%d must be a multiple of 8, <= 2048", (Cp))
+
+extern "C" int pp_colstats_bf16(const void* y, long long M, int Cp, float* partials, int nblk, pp_stream_t s) {
+  CHECK_CP(Cp, "pp_colstats_bf16");
+  PP_CHECK_ARG(M > 0 && nblk > 0, "pp_colstats_bf16: bad sizes");
+  const int rows_per_blk = (int)((M + nblk - 1) / nblk);
+  const int rpb = 256 / (Cp / 8);
+  hipLaunchKernelGGL(colstats_kernel, dim3(nblk), dim3(256), (size_t)rpb * 2 * Cp * 4, (hipStream_t)s, (const bfraw*)y, M,
+                     Cp, rows_per_blk, partials);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_bn_finalize(const float* partials, int nblk, int ldstat, long long count, int C, int Cp,
+                              const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                              float* running_var, float* mean, float* rstd, float* scale, float* shift, pp_stream_t s) {
+  PP_CHECK_ARG(C > 0 && Cp >= C && ldstat >= Cp && nblk > 0 && count > 0, "pp_bn_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 15) / 16), dim3(256), 0, (hipStream_t)s, partials, nblk, ldstat,
+                     (double)count, C, Cp, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_bn_apply(const void* y, const float* scale, const float* shift, const void* res, int relu, void* z,
+                           long long M, int Cp, pp_stream_t s) {
+  CHECK_CP(Cp, "pp_bn_apply");
+  const long long nchunks = M * (Cp / 8);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nchunks)), dim3(256), 0, (hipStream_t)s, (const bfraw*)y, scale,
+                     shift, (const bfraw*)res, relu, (bfraw*)z, nchunks, Cp / 8);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
+                                int relu, float* partials, int nblk, long long M, int Cp, pp_stream_t s) {
+  CHECK_CP(Cp, "pp_bn_bwd_reduce");
+  PP_CHECK_ARG(!relu || z, "pp_bn_bwd_reduce: relu needs z");
+  const int rows_per_blk = (int)((M + nblk - 1) / nblk);
+  const int rpb = 256 / (Cp / 8);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), (size_t)rpb * 2 * Cp * 4, (hipStream_t)s,
+                     (const bfraw*)dz, (const bfraw*)y, (const bfraw*)z, mean, rstd, relu, M, Cp, rows_per_blk, partials);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_bn_bwd_finalize(const float* partials, int nblk, long long count, int C, int Cp, const float* gamma,
+                                  const float* rstd, float* dgamma, float* dbeta, float* coef, pp_stream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Cp + 15) / 16), dim3(256), 0, (hipStream_t)s, partials, nblk,
+                     (double)count, C, Cp, gamma, rstd, dgamma, dbeta, coef);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
+                               const float* coef, int relu, void* dy, void* dres, long long M, int Cp, pp_stream_t s) {
+  CHECK_CP(Cp, "pp_bn_bwd_apply");
+  const long long nchunks = M * (Cp / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nchunks)), dim3(256), 0, (hipStream_t)s, (const bfraw*)dz,
+                     (const bfraw*)y, (const bfraw*)z, mean, rstd, coef, relu, (bfraw*)dy, (bfraw*)dres, nchunks, Cp / 8, Cp);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

@@ -1,0 +1,113 @@
+// Shared device helpers for the gfx950 (MI355X) kernels of libpeppa_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/peppa_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bfraw;  // raw bf16 bits in HBM
+
+#define PP_WAVE 64
+
+// ---- error plumbing (never throws, never syncs) -------------------------------------
+void pp_set_error(const char* fmt, ...);
+#define PP_CHECK_ARG(cond, ...)                        \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      pp_set_error(__VA_ARGS__);                       \
+      return PP_ERR_INVALID;                           \
+    }                                                  \
+  } while (0)
+#define PP_LAUNCH_CHECK()                                                  \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      pp_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__,       \
+                   hipGetErrorString(e_));                                 \
+      return PP_ERR_HIP;                                                   \
+    }                                                                      \
+  } while (0)
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bfraw v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bfraw f2bf(float f) {
+  // plain cast lowers to v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bfraw, b);
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack2(f[0], f[1]); v.y = pack2(f[2], f[3]);
+  v.z = pack2(f[4], f[5]); v.w = pack2(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- wave / block reductions ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// sum over a block of NW waves; `red` needs NW floats of LDS; result valid in all threads
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+
+// ---- exact unsigned division by an invariant (n < 2^31), host-prepared ------------------
+struct FastDiv {
+  uint32_t mul;
+  uint32_t shift;
+  uint32_t div;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.div = d;
+  if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+  uint32_t s = 0;
+  while ((1u << s) < d) ++s;  // ceil(log2 d)
+  uint64_t m = ((1ull << (32 + s)) + d - 1) / d;  // fits in 33 bits; valid for n < 2^31 when truncated? use 64-bit mul
+  f.mul = (uint32_t)(m - (1ull << 32));            // store low 32 bits of (m - 2^32)
+  f.shift = s;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  if (f.div == 1) return n;
+  // q = (n*m) >> (32+s) with m = 2^32 + mul  ->  ((mulhi(n,mul) + n) >> s), overflow-safe form
+  const uint32_t t = __umulhi(n, f.mul);
+  return (t + ((n - t) >> 1)) >> (f.shift - 1);
+}

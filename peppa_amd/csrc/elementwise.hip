@@ -1,0 +1,258 @@
+// Streaming / layout kernels (HBM-bound, 16-byte accesses) for libpeppa_hip.so (gfx950).
+#include "common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+void pp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* pp_last_error(void) { return g_err; }
+extern "C" int pp_version(void) { return 100; }
+
+namespace {
+
+inline int sgrid(long long n, int per = 256) {
+  long long b = (n + per - 1) / per;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+#define GSTRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+__global__ void gelu_fwd_kernel(const bfraw* __restrict__ x, bfraw* __restrict__ y, long long nch) {
+  GSTRIDE(i, nch) {
+    float f[8];
+    unpack8(*(const uint4*)(x + i * 8), f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] = gelu_f(f[q]);
+    *(uint4*)(y + i * 8) = pack8(f);
+  }
+}
+__global__ void gelu_bwd_kernel(const bfraw* __restrict__ dy, const bfraw* __restrict__ x, bfraw* __restrict__ dx,
+                                long long nch) {
+  GSTRIDE(i, nch) {
+    float f[8], d[8];
+    unpack8(*(const uint4*)(x + i * 8), f);
+    unpack8(*(const uint4*)(dy + i * 8), d);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] *= gelu_grad_f(f[q]);
+    *(uint4*)(dx + i * 8) = pack8(d);
+  }
+}
+__global__ void add_kernel(const bfraw* __restrict__ a, const bfraw* __restrict__ b, bfraw* __restrict__ o, long long nch) {
+  GSTRIDE(i, nch) {
+    float f[8], d[8];
+    unpack8(*(const uint4*)(a + i * 8), f);
+    unpack8(*(const uint4*)(b + i * 8), d);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] += d[q];
+    *(uint4*)(o + i * 8) = pack8(f);
+  }
+}
+__global__ void cast_f2b_kernel(const float* __restrict__ in, bfraw* __restrict__ out, long long n) {
+  GSTRIDE(i, n) out[i] = f2bf(in[i]);
+}
+__global__ void cast_b2f_kernel(const bfraw* __restrict__ in, float* __restrict__ out, long long n) {
+  GSTRIDE(i, n) out[i] = bf2f(in[i]);
+}
+__global__ void fill_kernel(float* p, float v, long long n) { GSTRIDE(i, n) p[i] = v; }
+
+__global__ void copy2d_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int ld_out, int rows,
+                              int cols) {
+  GSTRIDE(i, (long long)rows * cols) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    out[(long long)r * ld_out + c] = in[(long long)r * ld_in + c];
+  }
+}
+
+// out[r][c] (rows_out x ld_out, zero padded) = in[r][c] or in[c][r]
+__global__ void cast_pad_2d_kernel(const float* __restrict__ in, int rows, int cols, int ld_in, bfraw* __restrict__ out,
+                                   int rows_out, int ld_out, int transpose) {
+  GSTRIDE(i, (long long)rows_out * ld_out) {
+    const int r = (int)(i / ld_out), c = (int)(i % ld_out);
+    float v = 0.f;
+    if (r < rows && c < cols) v = transpose ? in[(long long)c * ld_in + r] : in[(long long)r * ld_in + c];
+    out[i] = f2bf(v);
+  }
+}
+
+// w [Co][Ci][taps] -> out[row][tap][cg]; row = co (or ci when transpose_io), channel = ci (or co)
+__global__ void prep_conv_kernel(const float* __restrict__ w, int Co, int Ci, int taps, bfraw* __restrict__ out,
+                                 int rows_out, int cg, int transpose_io, int flip, float scale) {
+  GSTRIDE(i, (long long)rows_out * taps * cg) {
+    const int c = (int)(i % cg);
+    const long long t2 = i / cg;
+    int tap = (int)(t2 % taps);
+    const int row = (int)(t2 / taps);
+    if (flip) tap = taps - 1 - tap;
+    const int co = transpose_io ? c : row, ci = transpose_io ? row : c;
+    float v = 0.f;
+    if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * taps + tap] * scale;
+    out[i] = f2bf(v);
+  }
+}
+__global__ void unprep_conv_kernel(const float* __restrict__ g, int Co, int Ci, int taps, int cg, float* __restrict__ dw) {
+  GSTRIDE(i, (long long)Co * Ci * taps) {
+    const int tap = (int)(i % taps);
+    const long long t2 = i / taps;
+    const int ci = (int)(t2 % Ci), co = (int)(t2 / Ci);
+    dw[i] = g[((long long)co * taps + tap) * cg + ci];
+  }
+}
+
+// batched bf16 transpose through LDS: in [R][ld_in] (C cols) -> out [C][ld_out] (R cols, zero padded)
+__global__ __launch_bounds__(256) void transpose_kernel(const bfraw* __restrict__ in, long long in_bs, int ld_in,
+                                                        bfraw* __restrict__ out, long long out_bs, int ld_out, int R, int C,
+                                                        int inner, long long in_s1, long long out_s1) {
+  __shared__ bfraw tile[32][33];
+  const int z = blockIdx.z;
+  const bfraw* ip = in + (z / inner) * in_bs + (z % inner) * in_s1;
+  bfraw* op = out + (z / inner) * out_bs + (z % inner) * out_s1;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < C) ? ip[(long long)r * ld_in + c] : (bfraw)0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < C && r < ld_out) op[(long long)c * ld_out + r] = tile[tx][k];
+  }
+}
+
+// x fp32 [B][3][T][H][W] -> out bf16 [B][T][H][W][8]
+__global__ void video_norm_kernel(const float* __restrict__ x, bfraw* __restrict__ out, long long npos, long long thw,
+                                  float m0, float m1, float m2, float i0, float i1, float i2) {
+  GSTRIDE(i, npos) {
+    const long long b = i / thw, p = i % thw;
+    const float* xp = x + b * 3 * thw + p;
+    float f[8] = {(xp[0] - m0) * i0, (xp[thw] - m1) * i1, (xp[2 * thw] - m2) * i2, 0, 0, 0, 0, 0};
+    *(uint4*)(out + i * 8) = pack8(f);
+  }
+}
+
+// column sums of bf16 [M][ld] -> out fp32 [N] (atomics over row slabs; out zeroed by the launcher)
+__global__ __launch_bounds__(256) void colsum_kernel(const bfraw* __restrict__ x, long long M, int N, int ld,
+                                                     int rows_per_blk, float* out) {
+  const int cpr = (N + 7) / 8;
+  const long long r0 = (long long)blockIdx.x * rows_per_blk;
+  long long r1 = r0 + rows_per_blk;
+  if (r1 > M) r1 = M;
+  for (int ch = threadIdx.x; ch < cpr; ch += 256) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long r = r0; r < r1; ++r) {
+      float f[8];
+      unpack8(*(const uint4*)(x + r * ld + ch * 8), f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += f[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (ch * 8 + q < N) atomicAdd(out + ch * 8 + q, acc[q]);
+  }
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)s)
+#define CHK8(n, who) PP_CHECK_ARG((n) > 0 && (n) % 8 == 0, who ": n=%lld must be a positive multiple of 8", (long long)(n))
+
+extern "C" int pp_gelu_fwd(const void* x, void* y, long long n, pp_stream_t s) {
+  CHK8(n, "pp_gelu_fwd");
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)x, (bfraw*)y, n / 8);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_gelu_bwd(const void* dy, const void* x, void* dx, long long n, pp_stream_t s) {
+  CHK8(n, "pp_gelu_bwd");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)dy, (const bfraw*)x, (bfraw*)dx, n / 8);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_add_bf16(const void* a, const void* b, void* out, long long n, pp_stream_t s) {
+  CHK8(n, "pp_add_bf16");
+  hipLaunchKernelGGL(add_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)a, (const bfraw*)b, (bfraw*)out, n / 8);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_cast_f32_to_bf16(const float* in, void* out, long long n, pp_stream_t s) {
+  PP_CHECK_ARG(n > 0, "pp_cast_f32_to_bf16: n");
+  hipLaunchKernelGGL(cast_f2b_kernel, dim3(sgrid(n)), dim3(256), 0, S_, in, (bfraw*)out, n);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_cast_bf16_to_f32(const void* in, float* out, long long n, pp_stream_t s) {
+  PP_CHECK_ARG(n > 0, "pp_cast_bf16_to_f32: n");
+  hipLaunchKernelGGL(cast_b2f_kernel, dim3(sgrid(n)), dim3(256), 0, S_, (const bfraw*)in, out, n);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_fill_f32(float* p, float v, long long n, pp_stream_t s) {
+  PP_CHECK_ARG(n > 0, "pp_fill_f32: n");
+  hipLaunchKernelGGL(fill_kernel, dim3(sgrid(n)), dim3(256), 0, S_, p, v, n);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_copy_2d_f32(const float* in, int ld_in, float* out, int ld_out, int rows, int cols, pp_stream_t s) {
+  PP_CHECK_ARG(rows > 0 && cols > 0, "pp_copy_2d_f32: sizes");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(sgrid((long long)rows * cols)), dim3(256), 0, S_, in, ld_in, out, ld_out, rows, cols);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_cast_pad_2d(const float* in, int rows, int cols, int ld_in, void* out, int rows_out, int ld_out,
+                              int transpose, pp_stream_t s) {
+  PP_CHECK_ARG(rows > 0 && cols > 0 && rows_out > 0 && ld_out > 0, "pp_cast_pad_2d: sizes");
+  hipLaunchKernelGGL(cast_pad_2d_kernel, dim3(sgrid((long long)rows_out * ld_out)), dim3(256), 0, S_, in, rows, cols, ld_in,
+                     (bfraw*)out, rows_out, ld_out, transpose);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, void* out, int rows_out, int cg,
+                                   int transpose_io, int flip, float scale, pp_stream_t s) {
+  PP_CHECK_ARG(Co > 0 && Ci > 0 && taps > 0 && rows_out > 0 && cg > 0 && cg % 8 == 0, "pp_prep_conv_weight: sizes");
+  PP_CHECK_ARG(transpose_io ? (rows_out >= Ci && cg >= Co) : (rows_out >= Co && cg >= Ci), "pp_prep_conv_weight: pad too small");
+  hipLaunchKernelGGL(prep_conv_kernel, dim3(sgrid((long long)rows_out * taps * cg)), dim3(256), 0, S_, w, Co, Ci, taps,
+                     (bfraw*)out, rows_out, cg, transpose_io, flip, scale);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_unprep_conv_grad(const float* g, int Co, int Ci, int taps, int cg, float* dw, pp_stream_t s) {
+  PP_CHECK_ARG(Co > 0 && Ci > 0 && taps > 0 && cg >= Ci, "pp_unprep_conv_grad: sizes");
+  hipLaunchKernelGGL(unprep_conv_kernel, dim3(sgrid((long long)Co * Ci * taps)), dim3(256), 0, S_, g, Co, Ci, taps, cg, dw);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_transpose_bf16(const void* in, long long in_bs, int ld_in, void* out, long long out_bs, int ld_out, int nb,
+                                 int R, int C, int inner, long long in_s1, long long out_s1, pp_stream_t s) {
+  PP_CHECK_ARG(nb > 0 && R > 0 && C > 0 && ld_out >= R && ld_in >= C, "pp_transpose_bf16: sizes");
+  if (inner <= 0) inner = 1;
+  dim3 grid((C + 31) / 32, (ld_out + 31) / 32, nb);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, S_, (const bfraw*)in, in_bs, ld_in, (bfraw*)out, out_bs, ld_out, R, C,
+                     inner, in_s1, out_s1);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_video_normalize_ndhwc(const float* x, void* out, int B, int T, int H, int W, const float* mean3,
+                                        const float* std3, pp_stream_t s) {
+  PP_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0 && mean3 && std3, "pp_video_normalize_ndhwc: sizes");
+  const long long thw = (long long)T * H * W;
+  hipLaunchKernelGGL(video_norm_kernel, dim3(sgrid(B * thw)), dim3(256), 0, S_, x, (bfraw*)out, B * thw, thw, mean3[0],
+                     mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_colsum_bf16(const void* x, long long M, int N, int ld, float* out, pp_stream_t s) {
+  PP_CHECK_ARG(M > 0 && N > 0 && ld % 8 == 0 && ld >= ((N + 7) & ~7), "pp_colsum_bf16: sizes");
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, S_);
+  if (e != hipSuccess) { pp_set_error("pp_colsum_bf16: memset failed"); return PP_ERR_HIP; }
+  int nblk = (int)((M + 63) / 64);
+  if (nblk > 1024) nblk = 1024;
+  const int rows_per_blk = (int)((M + nblk - 1) / nblk);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, S_, (const bfraw*)x, M, N, ld, rows_per_blk, out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

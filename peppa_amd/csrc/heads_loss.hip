@@ -1,0 +1,355 @@
+// fp32 tail of the step (gfx950): pooling heads, projection + L2-normalise, and the N x N
+// cosine-similarity triplet loss.  The contractions run on the exact-fp32 matrix instruction
+// v_mfma_f32_16x16x4_f32 from LDS-staged tiles; reductions are wave-64 shuffles.
+//   pig/models.py:30-43  Attention      pig/models.py:213-221 VideoAttention
+//   pig/models.py:106-109 / 148-150     project + F.normalize
+//   pig/loss.py:33-55    TripletLoss = contrastive(cosine_matrix(V, A))
+#include "common.h"
+
+namespace {
+
+// C(m,n) (+)= act(sum_k A(m,k) B(k,n) + bias[n]); arbitrary strides (transposes by stride).
+struct SG {
+  const float* A; long long sa_m, sa_k;
+  const float* B; long long sb_k, sb_n;
+  float* C; long long sc_m, sc_n;
+  int M, N, K;
+  const float* bias;
+  const float* aux;   // act==2: C = acc * (1 - aux^2), aux indexed like C
+  int act;            // 0 none, 1 tanh, 2 tanh-grad
+  int beta;           // 1: C += result (non-atomic)
+  int ksplit;         // >1: atomicAdd partial results into zeroed C
+};
+
+__global__ __launch_bounds__(256) void sgemm_kernel(const SG p) {
+  __shared__ float As[32][17];
+  __shared__ float Bs[16][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int kchunk = ((p.K + p.ksplit - 1) / p.ksplit + 15) & ~15;
+  const int kb = blockIdx.z * kchunk;
+  const int ke = min(p.K, kb + kchunk);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kb; k0 < ke; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i;
+      {  // A tile 32 x 16
+        const int r = e >> 4, c = e & 15;
+        const int m = m0 + r, k = k0 + c;
+        As[r][c] = (m < p.M && k < ke) ? p.A[m * p.sa_m + k * p.sa_k] : 0.f;
+      }
+      {  // B tile 16 x 32
+        const int r = e >> 5, c = e & 31;
+        const int k = k0 + r, n = n0 + c;
+        Bs[r][c] = (k < ke && n < p.N) ? p.B[k * p.sb_k + n * p.sb_n] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float a = As[wm * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+      const float b = Bs[kk * 4 + (lane >> 4)][wn * 16 + (lane & 15)];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + wn * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + wm * 16 + (lane >> 4) * 4 + r;
+    if (m < p.M && n < p.N) {
+      float v = acc[r];
+      if (p.bias && blockIdx.z == 0) v += p.bias[n];
+      float* cp = p.C + m * p.sc_m + n * p.sc_n;
+      if (p.ksplit > 1) { atomicAdd(cp, v); continue; }
+      if (p.act == 1) v = tanhf(v);
+      else if (p.act == 2) { const float h = p.aux[m * p.sc_m + n * p.sc_n]; v *= (1.f - h * h); }
+      if (p.beta) v += *cp;
+      *cp = v;
+    }
+  }
+}
+
+int sgemm(hipStream_t s, const float* A, long long sa_m, long long sa_k, const float* B, long long sb_k, long long sb_n, float* C,
+          long long sc_m, long long sc_n, int M, int N, int K, const float* bias = nullptr, int act = 0, const float* aux = nullptr,
+          int beta = 0, int ksplit = 1) {
+  SG p{A, sa_m, sa_k, B, sb_k, sb_n, C, sc_m, sc_n, M, N, K, bias, aux, act, beta, ksplit};
+  if (ksplit > 1) {
+    if (act != 0 || beta != 0 || sc_n != 1 || sc_m != N) { pp_set_error("sgemm: split-K needs dense plain output"); return PP_ERR_INVALID; }
+    if (hipMemsetAsync(C, 0, (size_t)M * N * 4, s) != hipSuccess) { pp_set_error("sgemm: memset failed"); return PP_ERR_HIP; }
+  }
+  hipLaunchKernelGGL(sgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, ksplit), dim3(256), 0, s, p);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+inline int pick_ksplit(int M, int N, int K) {
+  const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
+  int ks = 512 / (tiles > 0 ? tiles : 1);
+  const int maxk = (K + 63) / 64;
+  if (ks > maxk) ks = maxk;
+  return ks < 1 ? 1 : ks;
+}
+
+// out[n] = sum_m X[m*ld + n]   (fp32, N <= a few thousand, M arbitrary) -- atomics over row slabs
+__global__ void colsum_f32_kernel(const float* __restrict__ X, int M, int N, int ld, int rows_per_blk, float* out) {
+  const int r0 = blockIdx.x * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += X[(long long)r * ld + n];
+    atomicAdd(out + n, s);
+  }
+}
+int colsum_f32(hipStream_t s, const float* X, int M, int N, int ld, float* out) {
+  if (hipMemsetAsync(out, 0, (size_t)N * 4, s) != hipSuccess) { pp_set_error("colsum_f32: memset failed"); return PP_ERR_HIP; }
+  const int rpb = 32;
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, s, X, M, N, ld, rpb, out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---- spatial mean over HW (VideoAttention.spatial_avg) -----------------------------------------
+__global__ void spatial_mean_fwd_kernel(const bfraw* __restrict__ x, float* __restrict__ out, int HW, int C, int Cp) {
+  const long long bt = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += bf2f(x[(bt * HW + p) * Cp + c]);
+    out[bt * C + c] = s / HW;
+  }
+}
+__global__ void spatial_mean_bwd_kernel(const float* __restrict__ dout, bfraw* __restrict__ dx, int HW, int C, int Cp) {
+  const long long bt = blockIdx.x;
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    const bfraw v = f2bf(c < C ? dout[bt * C + c] / HW : 0.f);
+    for (int p = 0; p < HW; ++p) dx[(bt * HW + p) * Cp + c] = v;
+  }
+}
+
+// ---- softmax over time per feature + weighted sum ------------------------------------------------
+// e/alpha [B][T][F] in place; pooled[b][f] = sum_t alpha*x
+__global__ void timepool_fwd_kernel(float* __restrict__ ea, const float* __restrict__ x, float* __restrict__ pooled, int T, int F) {
+  const int b = blockIdx.x;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float* e = ea + (long long)b * T * F + f;
+    const float* xp = x + (long long)b * T * F + f;
+    float mx = -3.0e38f;
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, e[(long long)t * F]);
+    float sum = 0.f;
+    for (int t = 0; t < T; ++t) { const float v = __expf(e[(long long)t * F] - mx); e[(long long)t * F] = v; sum += v; }
+    const float inv = 1.f / sum;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) { const float a = e[(long long)t * F] * inv; e[(long long)t * F] = a; acc += a * xp[(long long)t * F]; }
+    pooled[(long long)b * F + f] = acc;
+  }
+}
+// de[t][f] = alpha*(dalpha - sum_t alpha*dalpha), dalpha = dpooled*x ; dx = dpooled*alpha
+__global__ void timepool_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ x, const float* __restrict__ dpooled,
+                                    float* __restrict__ de, float* __restrict__ dx, int T, int F) {
+  const int b = blockIdx.x;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    const long long o = (long long)b * T * F + f;
+    const float dp = dpooled[(long long)b * F + f];
+    float dot = 0.f;
+    for (int t = 0; t < T; ++t) dot += alpha[o + (long long)t * F] * dp * x[o + (long long)t * F];
+    for (int t = 0; t < T; ++t) {
+      const float a = alpha[o + (long long)t * F];
+      de[o + (long long)t * F] = a * (dp * x[o + (long long)t * F] - dot);
+      dx[o + (long long)t * F] = dp * a;
+    }
+  }
+}
+
+// ---- row L2 normalise (F.normalize: x / max(||x||, eps)) -----------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ nrm,
+                                                         int D, float eps) {
+  __shared__ float red[4];
+  const long long r = blockIdx.x;
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) { const float v = x[r * D + d]; s += v * v; }
+  const float n = sqrtf(block_sum<4>(s, red));
+  const float dn = fmaxf(n, eps);
+  for (int d = threadIdx.x; d < D; d += 256) y[r * D + d] = x[r * D + d] / dn;
+  if (nrm && threadIdx.x == 0) nrm[r] = n;
+}
+// dx = (dy - y*(y.dy)) / max(||x||,eps)   (for ||x|| >= eps; below eps the clamp makes it dy/eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ y, float* __restrict__ dx, int D, float eps) {
+  __shared__ float red[4];
+  const long long r = blockIdx.x;
+  float s = 0.f, dot = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) { const float v = x[r * D + d]; s += v * v; dot += y[r * D + d] * dy[r * D + d]; }
+  const float n = sqrtf(block_sum<4>(s, red));
+  dot = block_sum<4>(dot, red);
+  const bool clamped = n < eps;
+  const float dn = fmaxf(n, eps);
+  for (int d = threadIdx.x; d < D; d += 256)
+    dx[r * D + d] = clamped ? dy[r * D + d] / dn : (dy[r * D + d] - y[r * D + d] * dot) / dn;
+}
+
+__global__ void copy_f32_kernel(const float* a, float* b, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) b[i] = a[i];
+}
+
+// ---- triplet loss ----------------------------------------------------------------------------------
+// ws layout (floats): Vn[N*D] An[N*D] S/G[N*N] diag[N] rowcnt[N] colcnt[N] vnorm[N] anorm[N] dVn[N*D] dAn[N*D]
+struct LossWs {
+  float *Vn, *An, *G, *diag, *rowc, *colc, *vnorm, *anorm, *dVn, *dAn;
+};
+__host__ __device__ inline LossWs loss_ws(void* ws, int N, int D) {
+  LossWs w;
+  float* p = (float*)ws;
+  w.Vn = p; p += (size_t)N * D;
+  w.An = p; p += (size_t)N * D;
+  w.G = p; p += (size_t)N * N;
+  w.diag = p; p += N;
+  w.rowc = p; p += N;
+  w.colc = p; p += N;
+  w.vnorm = p; p += N;
+  w.anorm = p; p += N;
+  w.dVn = p; p += (size_t)N * D;
+  w.dAn = p; p += (size_t)N * D;
+  return w;
+}
+
+__global__ void diag_kernel(const float* __restrict__ S, float* diag, float* rowc, float* colc, float* loss, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { diag[i] = S[(long long)i * N + i]; rowc[i] = 0.f; colc[i] = 0.f; }
+  if (i == 0) loss[0] = 0.f;
+}
+// one block per row i of S: hinge terms, G (in place of S), indicator counts, loss partial
+__global__ __launch_bounds__(256) void hinge_kernel(float* __restrict__ SG_, const float* __restrict__ diag, float* rowc,
+                                                    float* colc, float* loss, int N, float margin) {
+  __shared__ float red[4];
+  const int i = blockIdx.x;
+  const float di = diag[i];
+  const float inv = 1.f / ((float)N * (float)N);
+  float part = 0.f, rc = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const float sij = SG_[(long long)i * N + j];
+    float g = 0.f;
+    if (j != i) {
+      const float hc = margin + sij - diag[j];   // column direction: against S_jj
+      const float hr = margin + sij - di;        // row direction: against S_ii
+      if (hc > 0.f) { part += hc; g += inv; atomicAdd(colc + j, 1.f); }
+      if (hr > 0.f) { part += hr; g += inv; rc += 1.f; }
+    }
+    SG_[(long long)i * N + j] = g;
+  }
+  part = block_sum<4>(part, red);
+  rc = block_sum<4>(rc, red);
+  if (threadIdx.x == 0) { atomicAdd(loss, part * inv); rowc[i] = rc; }
+}
+__global__ void gdiag_kernel(float* G, const float* rowc, const float* colc, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) G[(long long)i * N + i] = -(rowc[i] + colc[i]) / ((float)N * (float)N);
+}
+// dX = dloss * (dXn - Xn*(Xn.dXn)) / ||X||   (cosine_matrix normalisation, no clamp: pig/loss.py:51-55)
+__global__ __launch_bounds__(256) void cosnorm_bwd_kernel(const float* __restrict__ dXn, const float* __restrict__ Xn,
+                                                          const float* __restrict__ nrm, const float* __restrict__ dloss,
+                                                          float* __restrict__ dX, int D) {
+  __shared__ float red[4];
+  const long long r = blockIdx.x;
+  float dot = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) dot += Xn[r * D + d] * dXn[r * D + d];
+  dot = block_sum<4>(dot, red);
+  const float sc = dloss[0] / nrm[r];
+  for (int d = threadIdx.x; d < D; d += 256) dX[r * D + d] = sc * (dXn[r * D + d] - Xn[r * D + d] * dot);
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)s)
+#define RC(x) do { int rc_ = (x); if (rc_ != PP_OK) return rc_; } while (0)
+
+extern "C" int pp_spatial_mean_fwd(const void* x, float* out, int B, int T, int HW, int C, int Cp, pp_stream_t s) {
+  PP_CHECK_ARG(B > 0 && T > 0 && HW > 0 && C > 0 && Cp >= C, "pp_spatial_mean_fwd: sizes");
+  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(B * T), dim3(256), 0, S_, (const bfraw*)x, out, HW, C, Cp);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_spatial_mean_bwd(const float* dout, void* dx, int B, int T, int HW, int C, int Cp, pp_stream_t s) {
+  PP_CHECK_ARG(B > 0 && T > 0 && HW > 0 && C > 0 && Cp >= C, "pp_spatial_mean_bwd: sizes");
+  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(B * T), dim3(256), 0, S_, dout, (bfraw*)dx, HW, C, Cp);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" size_t pp_attnpool_ws_floats(int B, int T, int F, int Hd, int E) {
+  return (size_t)B * E + (size_t)B * F + (size_t)B * T * F + (size_t)B * T * Hd;
+}
+
+extern "C" int pp_attnpool_fwd(const float* x, int B, int T, int F, int Hd, int E, const float* W1, const float* b1,
+                               const float* W2, const float* b2, const float* Wp, const float* bp, float* hid, float* alpha,
+                               float* pooled, float* pre, float* out, pp_stream_t s) {
+  PP_CHECK_ARG(B > 0 && T > 0 && F > 0 && Hd > 0 && E > 0 && (Wp || E == F), "pp_attnpool_fwd: sizes");
+  const int BT = B * T;
+  RC(sgemm(S_, x, F, 1, W1, 1, F, hid, Hd, 1, BT, Hd, F, b1, 1));
+  RC(sgemm(S_, hid, Hd, 1, W2, 1, Hd, alpha, F, 1, BT, F, Hd, b2, 0));
+  hipLaunchKernelGGL(timepool_fwd_kernel, dim3(B), dim3(F < 256 ? ((F + 63) / 64) * 64 : 256), 0, S_, alpha, x, pooled, T, F);
+  if (Wp) RC(sgemm(S_, pooled, F, 1, Wp, 1, F, pre, E, 1, B, E, F, bp, 0));
+  else hipLaunchKernelGGL(copy_f32_kernel, dim3((B * E + 255) / 256), dim3(256), 0, S_, pooled, pre, (long long)B * E);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(256), 0, S_, pre, out, (float*)nullptr, E, 1e-12f);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_attnpool_bwd(const float* dout, const float* x, int B, int T, int F, int Hd, int E, const float* W1,
+                               const float* W2, const float* Wp, const float* hid, const float* alpha, const float* pooled,
+                               const float* pre, const float* out, float* dx, float* dW1, float* db1, float* dW2, float* db2,
+                               float* dWp, float* dbp, float* ws, pp_stream_t s) {
+  PP_CHECK_ARG(B > 0 && T > 0 && F > 0 && Hd > 0 && E > 0 && ws && (Wp || E == F), "pp_attnpool_bwd: sizes");
+  const int BT = B * T;
+  float* dpre = ws;
+  float* dpooled = dpre + (size_t)B * E;
+  float* de = dpooled + (size_t)B * F;
+  float* da = de + (size_t)BT * F;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, S_, dout, pre, out, dpre, E, 1e-12f);
+  if (Wp) {
+    RC(sgemm(S_, dpre, 1, E, pooled, F, 1, dWp, F, 1, E, F, B));            // dWp[e][f] = sum_b dpre[b][e] pooled[b][f]
+    RC(colsum_f32(S_, dpre, B, E, E, dbp));
+    RC(sgemm(S_, dpre, E, 1, Wp, F, 1, dpooled, F, 1, B, F, E));            // dpooled = dpre Wp
+  } else {
+    hipLaunchKernelGGL(copy_f32_kernel, dim3((B * E + 255) / 256), dim3(256), 0, S_, dpre, dpooled, (long long)B * E);
+  }
+  hipLaunchKernelGGL(timepool_bwd_kernel, dim3(B), dim3(F < 256 ? ((F + 63) / 64) * 64 : 256), 0, S_, alpha, x, dpooled, de, dx, T, F);
+  RC(sgemm(S_, de, 1, F, hid, Hd, 1, dW2, Hd, 1, F, Hd, BT, nullptr, 0, nullptr, 0, pick_ksplit(F, Hd, BT)));   // dW2[f][h]
+  RC(colsum_f32(S_, de, BT, F, F, db2));
+  RC(sgemm(S_, de, F, 1, W2, Hd, 1, da, Hd, 1, BT, Hd, F, nullptr, 2, hid));  // da = (de W2) * (1 - hid^2)
+  RC(sgemm(S_, da, 1, Hd, x, F, 1, dW1, F, 1, Hd, F, BT, nullptr, 0, nullptr, 0, pick_ksplit(Hd, F, BT)));       // dW1[h][f]
+  RC(colsum_f32(S_, da, BT, Hd, Hd, db1));
+  RC(sgemm(S_, da, Hd, 1, W1, F, 1, dx, F, 1, BT, F, Hd, nullptr, 0, nullptr, 1));  // dx += da W1
+  return PP_OK;
+}
+
+extern "C" size_t pp_triplet_workspace_bytes(int N, int D) {
+  return ((size_t)4 * N * D + (size_t)N * N + 5 * (size_t)N) * sizeof(float);
+}
+
+extern "C" int pp_triplet_loss_fwd(const float* V, const float* A, int N, int D, float margin, float* loss, void* ws,
+                                   size_t ws_bytes, pp_stream_t s) {
+  PP_CHECK_ARG(N > 0 && D > 0 && V && A && loss && ws, "pp_triplet_loss_fwd: bad arguments");
+  PP_CHECK_ARG(ws_bytes >= pp_triplet_workspace_bytes(N, D), "pp_triplet_loss_fwd: workspace too small");
+  const LossWs w = loss_ws(ws, N, D);
+  // cosine_matrix: U / ||U|| without clamp (eps = 0), pig/loss.py:51-55
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(N), dim3(256), 0, S_, V, w.Vn, w.vnorm, D, 0.f);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(N), dim3(256), 0, S_, A, w.An, w.anorm, D, 0.f);
+  RC(sgemm(S_, w.Vn, D, 1, w.An, 1, D, w.G, N, 1, N, N, D));  // S = Vn An^T
+  hipLaunchKernelGGL(diag_kernel, dim3((N + 255) / 256), dim3(256), 0, S_, w.G, w.diag, w.rowc, w.colc, loss, N);
+  hipLaunchKernelGGL(hinge_kernel, dim3(N), dim3(256), 0, S_, w.G, w.diag, w.rowc, w.colc, loss, N, margin);
+  hipLaunchKernelGGL(gdiag_kernel, dim3((N + 255) / 256), dim3(256), 0, S_, w.G, w.rowc, w.colc, N);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_triplet_loss_bwd(const float* V, const float* A, int N, int D, const float* dloss, const void* ws,
+                                   float* dV, float* dA, pp_stream_t s) {
+  PP_CHECK_ARG(N > 0 && D > 0 && V && A && dloss && ws && dV && dA, "pp_triplet_loss_bwd: bad arguments");
+  const LossWs w = loss_ws((void*)ws, N, D);
+  RC(sgemm(S_, w.G, N, 1, w.An, D, 1, w.dVn, D, 1, N, D, N));   // dVn = G An
+  RC(sgemm(S_, w.G, 1, N, w.Vn, D, 1, w.dAn, D, 1, N, D, N));   // dAn = G^T Vn
+  hipLaunchKernelGGL(cosnorm_bwd_kernel, dim3(N), dim3(256), 0, S_, w.dVn, w.Vn, w.vnorm, dloss, dV, D);
+  hipLaunchKernelGGL(cosnorm_bwd_kernel, dim3(N), dim3(256), 0, S_, w.dAn, w.An, w.anorm, dloss, dA, D);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

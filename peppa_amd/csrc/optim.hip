@@ -1,0 +1,68 @@
+// Fused multi-tensor BertAdam step (gfx950, HBM-bound: 28 B/param).
+// Restates pig/optimization.py:101-179: per-tensor clip_grad_norm_(p, max_grad_norm) (coef =
+// max_norm/(norm+1e-6), clamped to 1), m = b1*m + (1-b1)*g, v = b2*v + (1-b2)*g*g,
+// update = m/(sqrt(v)+eps) + wd*p, p -= lr_scheduled*update; no bias correction.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const pp_tensor_list tl, const int* __restrict__ chunk_tensor,
+                                                    const long long* __restrict__ chunk_off, int chunk, float* norms) {
+  __shared__ float red[4];
+  const int t = chunk_tensor[blockIdx.x];
+  const long long off = chunk_off[blockIdx.x];
+  const long long n = tl.numel[t];
+  const float* g = tl.g[t];
+  const long long end = off + chunk < n ? off + chunk : n;
+  float s = 0.f;
+  for (long long i = off + threadIdx.x; i < end; i += 256) { const float v = g[i]; s += v * v; }
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) atomicAdd(norms + t, s);
+}
+
+__global__ __launch_bounds__(256) void bertadam_kernel(const pp_tensor_list tl, const int* __restrict__ chunk_tensor,
+                                                       const long long* __restrict__ chunk_off, int chunk,
+                                                       const float* __restrict__ norms, float lr, float b1, float b2, float eps,
+                                                       float wd, float max_norm) {
+  const int t = chunk_tensor[blockIdx.x];
+  const long long off = chunk_off[blockIdx.x];
+  const long long n = tl.numel[t];
+  float* p = tl.p[t];
+  const float* g = tl.g[t];
+  float* m = tl.m[t];
+  float* v = tl.v[t];
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    coef = max_norm / (sqrtf(norms[t]) + 1e-6f);
+    coef = coef < 1.f ? coef : 1.f;
+  }
+  const long long end = off + chunk < n ? off + chunk : n;
+  for (long long i = off + threadIdx.x; i < end; i += 256) {
+    const float gi = g[i] * coef;
+    const float mi = m[i] * b1 + (1.f - b1) * gi;
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    float upd = mi / (sqrtf(vi) + eps);
+    const float pi = p[i];
+    if (wd > 0.f) upd += wd * pi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - lr * upd;
+  }
+}
+
+}  // namespace
+
+extern "C" int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off, int n_chunks,
+                                int chunk, float* norms, float lr_scheduled, float b1, float b2, float eps, float weight_decay,
+                                float max_grad_norm, pp_stream_t s) {
+  PP_CHECK_ARG(tl && tl->n_tensors > 0 && n_chunks > 0 && chunk > 0 && norms, "pp_bertadam_step: bad arguments");
+  hipStream_t st = (hipStream_t)s;
+  if (max_grad_norm > 0.f) {
+    if (hipMemsetAsync(norms, 0, (size_t)tl->n_tensors * 4, st) != hipSuccess) { pp_set_error("pp_bertadam_step: memset"); return PP_ERR_HIP; }
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms);
+  }
+  hipLaunchKernelGGL(bertadam_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms, lr_scheduled,
+                     b1, b2, eps, weight_decay, max_grad_norm);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

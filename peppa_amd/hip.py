@@ -1,0 +1,274 @@
+"""Tensor-level wrappers over the C ABI (include/peppa_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function below
+passes raw pointers + the current HIP stream to libpeppa_hip.so.  Nothing in this module
+computes with torch ops, and there is no fallback when a tensor is not on the GPU.
+"""
+import ctypes as C
+import torch
+
+from ._lib import call, Gather, IGemmDesc, WGradDesc, TensorList, PeppaHipError
+
+DENSE, CONV_FWD, CONV_DGRAD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PeppaHipError("peppa_amd kernels need CUDA/HIP tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise PeppaHipError(f"expected dtype {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def gather_dense(lda):
+    g = Gather()
+    g.mode, g.lda = DENSE, lda
+    g.Rt = g.Rh = g.Rw = g.Gt = g.Gh = g.Gw = g.kt = g.kh = g.kw = g.st = g.sh = g.sw = 1
+    return g
+
+
+def gather_conv(mode, R, G, k, s, p, cg, cstride):
+    g = Gather()
+    g.mode, g.lda = mode, 0
+    g.Rt, g.Rh, g.Rw = R
+    g.Gt, g.Gh, g.Gw = G
+    g.kt, g.kh, g.kw = k
+    g.st, g.sh, g.sw = s
+    g.pt, g.ph, g.pw = p
+    g.cg, g.cstride = cg, cstride
+    return g
+
+
+def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NONE, residual=None, ldr=0,
+          Cpre=None, colstats=None, ldstat=0, nbatch=1, inner=1, a_s=(0, 0), b_s=(0, 0), c_s=(0, 0),
+          bias_s=(0, 0)):
+    d = IGemmDesc()
+    d.M, d.N, d.K, d.g = M, N, K, g
+    d.A, d.Bt, d.ldb, d.b_rows = _p(A, bf16), _p(Bt, bf16), ldb, b_rows
+    d.C, d.ldc, d.c_fp32 = _p(Cout), ldc, int(Cout.dtype == f32)
+    d.Cpre = _p(Cpre, bf16)
+    d.bias, d.act = _p(bias, f32), act
+    d.residual, d.ldr = _p(residual, bf16), ldr
+    d.colstats, d.ldstat = _p(colstats, f32), ldstat
+    d.nbatch, d.inner = nbatch, inner
+    d.a_s0, d.a_s1 = a_s
+    d.b_s0, d.b_s1 = b_s
+    d.c_s0, d.c_s1 = c_s
+    d.bias_s0, d.bias_s1 = bias_s
+    call("pp_igemm", C.byref(d), _s())
+
+
+def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0):
+    d = WGradDesc()
+    d.M, d.Ni, d.Kj, d.g = M, Ni, Kj, g
+    d.X, d.dY, d.ldy, d.dW, d.ldw = _p(X, bf16), _p(dY, bf16), ldy, _p(dW, f32), ldw
+    d.msplit, d.nbatch, d.x_s, d.dy_s, d.dw_s = msplit, nbatch, x_s, dy_s, dw_s
+    call("pp_wgrad", C.byref(d), _s())
+
+
+# ---- weight preparation ----------------------------------------------------------------------
+def prep_conv_weight(w, out, Co, Ci, taps, rows_out, cg, transpose_io=False, flip=False, scale=1.0):
+    call("pp_prep_conv_weight", _p(w, f32), Co, Ci, taps, _p(out, bf16), rows_out, cg, int(transpose_io), int(flip),
+         scale, _s())
+
+
+def unprep_conv_grad(g, dw, Co, Ci, taps, cg):
+    call("pp_unprep_conv_grad", _p(g, f32), Co, Ci, taps, cg, _p(dw, f32), _s())
+
+
+def cast_pad_2d(inp, out, rows, cols, ld_in, rows_out, ld_out, transpose=False):
+    call("pp_cast_pad_2d", _p(inp, f32), rows, cols, ld_in, _p(out, bf16), rows_out, ld_out, int(transpose), _s())
+
+
+def cast_f32_to_bf16(inp, out):
+    call("pp_cast_f32_to_bf16", _p(inp, f32), _p(out, bf16), inp.numel(), _s())
+
+
+def cast_bf16_to_f32(inp, out):
+    call("pp_cast_bf16_to_f32", _p(inp, bf16), _p(out, f32), inp.numel(), _s())
+
+
+def copy_2d_f32(inp, ld_in, out, ld_out, rows, cols):
+    call("pp_copy_2d_f32", _p(inp, f32), ld_in, _p(out, f32), ld_out, rows, cols, _s())
+
+
+def transpose_bf16(inp, in_bs, ld_in, out, out_bs, ld_out, nb, R, Ccols, inner=1, in_s1=0, out_s1=0):
+    call("pp_transpose_bf16", _p(inp, bf16), in_bs, ld_in, _p(out, bf16), out_bs, ld_out, nb, R, Ccols, inner,
+         in_s1, out_s1, _s())
+
+
+def fill_f32(t, v):
+    call("pp_fill_f32", _p(t, f32), float(v), t.numel(), _s())
+
+
+def video_normalize_ndhwc(x, out, mean3, std3):
+    B, _, T, H, W = x.shape
+    m = (C.c_float * 3)(*mean3)
+    sd = (C.c_float * 3)(*std3)
+    call("pp_video_normalize_ndhwc", _p(x, f32), _p(out, bf16), B, T, H, W, m, sd, _s())
+
+
+# ---- batch norm -----------------------------------------------------------------------------------
+def bn_finalize(partials, nblk, ldstat, count, Cn, Cp, gamma, beta, eps, momentum, rmean, rvar, mean, rstd,
+                scale, shift):
+    call("pp_bn_finalize", _p(partials, f32), nblk, ldstat, count, Cn, Cp, _p(gamma, f32), _p(beta, f32), eps,
+         momentum, _p(rmean, f32), _p(rvar, f32), _p(mean, f32), _p(rstd, f32), _p(scale, f32), _p(shift, f32), _s())
+
+
+def colstats_bf16(y, M, Cp, partials, nblk):
+    call("pp_colstats_bf16", _p(y, bf16), M, Cp, _p(partials, f32), nblk, _s())
+
+
+def bn_apply(y, scale, shift, res, relu, z, M, Cp):
+    call("pp_bn_apply", _p(y, bf16), _p(scale, f32), _p(shift, f32), _p(res, bf16), int(relu), _p(z, bf16), M, Cp, _s())
+
+
+def bn_bwd_reduce(dz, y, z, mean, rstd, relu, partials, nblk, M, Cp):
+    call("pp_bn_bwd_reduce", _p(dz, bf16), _p(y, bf16), _p(z, bf16), _p(mean, f32), _p(rstd, f32), int(relu),
+         _p(partials, f32), nblk, M, Cp, _s())
+
+
+def bn_bwd_finalize(partials, nblk, count, Cn, Cp, gamma, rstd, dgamma, dbeta, coef):
+    call("pp_bn_bwd_finalize", _p(partials, f32), nblk, count, Cn, Cp, _p(gamma, f32), _p(rstd, f32),
+         _p(dgamma, f32), _p(dbeta, f32), _p(coef, f32), _s())
+
+
+def bn_bwd_apply(dz, y, z, mean, rstd, coef, relu, dy, dres, M, Cp):
+    call("pp_bn_bwd_apply", _p(dz, bf16), _p(y, bf16), _p(z, bf16), _p(mean, f32), _p(rstd, f32), _p(coef, f32),
+         int(relu), _p(dy, bf16), _p(dres, bf16), M, Cp, _s())
+
+
+# ---- elementwise ----------------------------------------------------------------------------------
+def gelu_fwd(x, y):
+    call("pp_gelu_fwd", _p(x, bf16), _p(y, bf16), x.numel(), _s())
+
+
+def gelu_bwd(dy, x, dx):
+    call("pp_gelu_bwd", _p(dy, bf16), _p(x, bf16), _p(dx, bf16), x.numel(), _s())
+
+
+def add_bf16(a, b, out):
+    call("pp_add_bf16", _p(a, bf16), _p(b, bf16), _p(out, bf16), a.numel(), _s())
+
+
+def colsum_bf16(x, M, N, ld, out):
+    call("pp_colsum_bf16", _p(x, bf16), M, N, ld, _p(out, f32), _s())
+
+
+# ---- layer norm / softmax -------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, y, mean, rstd, rows, D):
+    call("pp_layernorm_fwd", _p(x, bf16), _p(gamma, f32), _p(beta, f32), eps, _p(y, bf16), _p(mean, f32),
+         _p(rstd, f32), rows, D, _s())
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D):
+    call("pp_layernorm_bwd", _p(dy, bf16), _p(x, bf16), _p(gamma, f32), _p(mean, f32), _p(rstd, f32), _p(dx, bf16),
+         _p(dgamma, f32), _p(dbeta, f32), rows, D, _s())
+
+
+def softmax_fwd(S, lds, P, ldp, nb, T, scale):
+    call("pp_softmax_fwd", _p(S, f32), lds, _p(P, bf16), ldp, nb, T, scale, _s())
+
+
+def softmax_bwd(dP, lds, P, ldp, dS, nb, T, scale):
+    call("pp_softmax_bwd", _p(dP, f32), lds, _p(P, bf16), ldp, _p(dS, bf16), nb, T, scale, _s())
+
+
+# ---- wav2vec2 conv0 + groupnorm, weight norm --------------------------------------------------------
+def conv0_stats(wave, B, L, T0, w, stats):
+    call("pp_conv0_stats", _p(wave, f32), B, L, T0, _p(w, f32), _p(stats, f32), _s())
+
+
+def conv0_apply(wave, B, L, T0, w, stats, gamma, beta, eps, out):
+    call("pp_conv0_apply", _p(wave, f32), B, L, T0, _p(w, f32), _p(stats, f32), _p(gamma, f32), _p(beta, f32), eps,
+         _p(out, bf16), _s())
+
+
+def conv0_bwd_reduce(wave, B, L, T0, w, stats, gamma, beta, eps, dout, red):
+    call("pp_conv0_bwd_reduce", _p(wave, f32), B, L, T0, _p(w, f32), _p(stats, f32), _p(gamma, f32), _p(beta, f32),
+         eps, _p(dout, bf16), _p(red, f32), _s())
+
+
+def conv0_bwd_apply(wave, B, L, T0, w, stats, gamma, beta, eps, dout, red, dw, dgamma, dbeta):
+    call("pp_conv0_bwd_apply", _p(wave, f32), B, L, T0, _p(w, f32), _p(stats, f32), _p(gamma, f32), _p(beta, f32),
+         eps, _p(dout, bf16), _p(red, f32), _p(dw, f32), _p(dgamma, f32), _p(dbeta, f32), _s())
+
+
+def weightnorm_fwd(v, g, Co, Ci, Kk, norm, out):
+    call("pp_weightnorm_fwd", _p(v, f32), _p(g, f32), Co, Ci, Kk, _p(norm, f32), _p(out, bf16), _s())
+
+
+def weightnorm_bwd(dwt, v, g, norm, Co, Ci, Kk, dv, dg, dot_ws):
+    call("pp_weightnorm_bwd", _p(dwt, f32), _p(v, f32), _p(g, f32), _p(norm, f32), Co, Ci, Kk, _p(dv, f32),
+         _p(dg, f32), _p(dot_ws, f32), _s())
+
+
+# ---- heads ------------------------------------------------------------------------------------------
+def spatial_mean_fwd(x, out, B, T, HW, Cn, Cp):
+    call("pp_spatial_mean_fwd", _p(x, bf16), _p(out, f32), B, T, HW, Cn, Cp, _s())
+
+
+def spatial_mean_bwd(dout, dx, B, T, HW, Cn, Cp):
+    call("pp_spatial_mean_bwd", _p(dout, f32), _p(dx, bf16), B, T, HW, Cn, Cp, _s())
+
+
+def attnpool_fwd(x, B, T, Fdim, Hd, E, W1, b1, W2, b2, Wp, bp, hid, alpha, pooled, pre, out):
+    call("pp_attnpool_fwd", _p(x, f32), B, T, Fdim, Hd, E, _p(W1, f32), _p(b1, f32), _p(W2, f32), _p(b2, f32),
+         _p(Wp, f32), _p(bp, f32), _p(hid, f32), _p(alpha, f32), _p(pooled, f32), _p(pre, f32), _p(out, f32), _s())
+
+
+def attnpool_ws_floats(B, T, Fdim, Hd, E):
+    return call("pp_attnpool_ws_floats", B, T, Fdim, Hd, E)
+
+
+def attnpool_bwd(dout, x, B, T, Fdim, Hd, E, W1, W2, Wp, hid, alpha, pooled, pre, out, dx, dW1, db1, dW2, db2, dWp,
+                 dbp, ws):
+    call("pp_attnpool_bwd", _p(dout, f32), _p(x, f32), B, T, Fdim, Hd, E, _p(W1, f32), _p(W2, f32), _p(Wp, f32),
+         _p(hid, f32), _p(alpha, f32), _p(pooled, f32), _p(pre, f32), _p(out, f32), _p(dx, f32), _p(dW1, f32),
+         _p(db1, f32), _p(dW2, f32), _p(db2, f32), _p(dWp, f32), _p(dbp, f32), _p(ws, f32), _s())
+
+
+# ---- loss ------------------------------------------------------------------------------------------
+def triplet_workspace_bytes(N, D):
+    return call("pp_triplet_workspace_bytes", N, D)
+
+
+def triplet_loss_fwd(V, A, margin, loss, ws):
+    N, D = V.shape
+    call("pp_triplet_loss_fwd", _p(V, f32), _p(A, f32), N, D, margin, _p(loss, f32), _p(ws), ws.numel() * ws.element_size(),
+         _s())
+
+
+def triplet_loss_bwd(V, A, dloss, ws, dV, dA):
+    N, D = V.shape
+    call("pp_triplet_loss_bwd", _p(V, f32), _p(A, f32), N, D, _p(dloss, f32), _p(ws), _p(dV, f32), _p(dA, f32), _s())
+
+
+# ---- optimizer -------------------------------------------------------------------------------------
+def bertadam_step(tl, chunk_tensor, chunk_off, n_chunks, chunk, norms, lr, b1, b2, eps, wd, max_norm):
+    call("pp_bertadam_step", C.byref(tl), _p(chunk_tensor, torch.int32), _p(chunk_off, torch.int64), n_chunks, chunk,
+         _p(norms, f32), lr, b1, b2, eps, wd, max_norm, _s())
+
+
+def make_tensor_list(ps, gs, ms, vs, device):
+    """Device-resident pointer tables for pp_bertadam_step; returns (TensorList, keepalive)."""
+    n = len(ps)
+    tab = torch.tensor([[t.data_ptr() for t in ps], [t.data_ptr() for t in gs], [t.data_ptr() for t in ms],
+                        [t.data_ptr() for t in vs], [t.numel() for t in ps]], dtype=torch.int64).to(device)
+    tl = TensorList()
+    tl.n_tensors = n
+    base = tab.data_ptr()
+    tl.p, tl.g, tl.m, tl.v, tl.numel = base, base + 8 * n, base + 16 * n, base + 24 * n, base + 32 * n
+    return tl, tab

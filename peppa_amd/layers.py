@@ -1,0 +1,228 @@
+"""Forward/backward primitives of the hot path, expressed over the C ABI (peppa_amd.hip).
+
+Each primitive is an explicit (forward, backward) pair on channels-last bf16 activations;
+the encoders (video.py / audio.py) chain them inside one autograd.Function per encoder, so
+activation buffers, weight operand layouts and streams are managed by hand instead of by a
+tracing compiler.  No torch arithmetic happens here: torch only allocates.
+"""
+import torch
+
+from . import hip as H
+from .hip import rup, bf16, f32
+
+CP = 16  # channel padding of activation tensors
+
+
+def cpad(c):
+    return rup(c, CP)
+
+
+def empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def zeros(shape, dtype, like):
+    return torch.zeros(shape, dtype=dtype, device=like.device)
+
+
+class ConvGeom:
+    """Geometry of one convolution on a channels-last tensor [B][Ti][Hi][Wi][cstride]."""
+
+    def __init__(self, B, in_thw, Ci, Co, k, s, p, groups=1, in_cstride=None, out_cstride=None, cg_in=None, To=None):
+        self.B, self.Ci, self.Co, self.k, self.s, self.p, self.groups = B, Ci, Co, tuple(k), tuple(s), tuple(p), groups
+        self.Ti, self.Hi, self.Wi = in_thw
+        self.To = To if To is not None else (self.Ti + 2 * p[0] - k[0]) // s[0] + 1  # To override: pos-conv drops its last frame
+        self.Ho = (self.Hi + 2 * p[1] - k[1]) // s[1] + 1
+        self.Wo = (self.Wi + 2 * p[2] - k[2]) // s[2] + 1
+        self.taps = k[0] * k[1] * k[2]
+        self.Cig, self.Cog = Ci // groups, Co // groups
+        # channels read per tap / written per group
+        self.cg_in = cg_in if cg_in is not None else (cpad(Ci) if groups == 1 else self.Cig)
+        self.cg_out = cpad(Co) if groups == 1 else self.Cog
+        self.in_cstride = in_cstride if in_cstride is not None else cpad(Ci)
+        self.out_cstride = out_cstride if out_cstride is not None else cpad(Co)
+        self.M = B * self.To * self.Ho * self.Wo
+        self.Min = B * self.Ti * self.Hi * self.Wi
+        self.Kf = self.taps * self.cg_in     # forward reduce length
+        self.Kd = self.taps * self.cg_out    # dgrad reduce length
+        self.nblk = (self.M + 127) // 128
+
+    @property
+    def out_thw(self):
+        return (self.To, self.Ho, self.Wo)
+
+    def g_fwd(self):
+        return H.gather_conv(H.CONV_FWD, (self.To, self.Ho, self.Wo), (self.Ti, self.Hi, self.Wi), self.k, self.s,
+                             self.p, self.cg_in, self.in_cstride)
+
+    def g_dgrad(self):
+        return H.gather_conv(H.CONV_DGRAD, (self.Ti, self.Hi, self.Wi), (self.To, self.Ho, self.Wo), self.k, self.s,
+                             self.p, self.cg_out, self.out_cstride)
+
+
+def prep_conv_weights(w, geom, need_dgrad=True):
+    """fp32 master [Co][Ci/groups][taps...] -> bf16 operands (forward, dgrad)."""
+    Co, Cig, taps = geom.Co, geom.Cig, geom.taps
+    wf = empty((Co, taps, geom.cg_in), bf16, w)
+    H.prep_conv_weight(w, wf, Co, Cig, taps, Co, geom.cg_in)
+    wd = None
+    if need_dgrad:
+        if geom.groups == 1:
+            wd = empty((geom.Ci, taps, geom.cg_out), bf16, w)
+            H.prep_conv_weight(w, wd, Co, geom.Ci, taps, geom.Ci, geom.cg_out, transpose_io=True)
+        else:
+            # per group g: rows = ci (Cig), reduce = (tap, co in group)
+            wd = empty((geom.groups, Cig, taps, geom.Cog), bf16, w)
+            for gi in range(geom.groups):
+                H.prep_conv_weight(w[gi * geom.Cog:(gi + 1) * geom.Cog], wd[gi], geom.Cog, Cig, taps, Cig, geom.Cog,
+                                   transpose_io=True)
+    return wf, wd
+
+
+def conv_fwd(x, geom, wf, *, stats=False, bias=None, act=H.ACT_NONE, out=None, pre=None):
+    """y[M][out_cstride] = conv(x); optional per-column partial sums for BatchNorm."""
+    y = out if out is not None else empty((geom.M, geom.out_cstride), bf16, x)
+    partials = empty((geom.nblk, 2, geom.out_cstride), f32, x) if stats else None
+    if geom.groups == 1:
+        H.igemm(x, wf, y, geom.M, geom.out_cstride, geom.Kf, geom.g_fwd(), geom.Kf, geom.out_cstride,
+                b_rows=geom.Co, bias=bias, act=act, Cpre=pre, colstats=partials, ldstat=geom.out_cstride)
+    else:
+        G = geom.groups
+        H.igemm(x, wf, y, geom.M, geom.Cog, geom.Kf, geom.g_fwd(), geom.Kf, geom.out_cstride, b_rows=geom.Cog,
+                bias=bias, act=act, Cpre=pre, nbatch=G, inner=1, a_s=(geom.Cig, 0), b_s=(geom.Cog * geom.Kf, 0),
+                c_s=(geom.Cog, 0), bias_s=(geom.Cog, 0))
+    return y, partials
+
+
+def conv_dgrad(dy, geom, wd, *, residual=None):
+    """dx[Min][in_cstride] = conv^T(dy) (+ residual)."""
+    dx = empty((geom.Min, geom.in_cstride), bf16, dy)
+    if geom.groups == 1:
+        H.igemm(dy, wd, dx, geom.Min, geom.in_cstride, geom.Kd, geom.g_dgrad(), geom.Kd, geom.in_cstride,
+                b_rows=geom.Ci, residual=residual, ldr=geom.in_cstride)
+    else:
+        assert residual is None
+        G = geom.groups
+        H.igemm(dy, wd, dx, geom.Min, geom.Cig, geom.Kd, geom.g_dgrad(), geom.Kd, geom.in_cstride, b_rows=geom.Cig,
+                nbatch=G, inner=1, a_s=(geom.Cog, 0), b_s=(geom.Cig * geom.Kd, 0), c_s=(geom.Cig, 0))
+    return dx
+
+
+def conv_wgrad_raw(x, dy, geom):
+    """fp32 gradient in operand layout [Co][taps][cg_in]."""
+    gw = zeros((geom.Co, geom.taps, geom.cg_in), f32, x)
+    if geom.groups == 1:
+        H.wgrad(x, dy, gw, geom.M, geom.Co, geom.Kf, geom.g_fwd(), geom.out_cstride, geom.Kf)
+    else:
+        H.wgrad(x, dy, gw, geom.M, geom.Cog, geom.Kf, geom.g_fwd(), geom.out_cstride, geom.Kf, nbatch=geom.groups,
+                x_s=geom.Cig, dy_s=geom.Cog, dw_s=geom.Cog * geom.Kf)
+    return gw
+
+
+def conv_wgrad(x, dy, geom, w_shape):
+    gw = conv_wgrad_raw(x, dy, geom)
+    dw = empty(w_shape, f32, x)
+    H.unprep_conv_grad(gw, dw, geom.Co, geom.Cig, geom.taps, geom.cg_in)
+    return dw
+
+
+# ---- BatchNorm (train mode) -------------------------------------------------------------------------
+class BNSaved:
+    __slots__ = ("mean", "rstd", "scale", "shift", "count", "C", "Cp")
+
+
+def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momentum=0.1, update_running=True):
+    """z = relu?(bn(y) (+residual)); `bn` has .weight .bias .running_mean .running_var."""
+    C = bn.weight.numel()
+    Cp = y.shape[1]
+    sv = BNSaved()
+    sv.count, sv.C, sv.Cp = count, C, Cp
+    sv.mean, sv.rstd, sv.scale, sv.shift = (empty((Cp,), f32, y) for _ in range(4))
+    H.bn_finalize(partials, nblk, Cp, count, C, Cp, bn.weight, bn.bias, eps, momentum,
+                  bn.running_mean if update_running else None, bn.running_var if update_running else None,
+                  sv.mean, sv.rstd, sv.scale, sv.shift)
+    z = empty(y.shape, bf16, y)
+    H.bn_apply(y, sv.scale, sv.shift, residual, relu, z, y.shape[0], Cp)
+    return z, sv
+
+
+def bn_bwd(dz, y, z, sv, gamma, *, relu, want_dres=False):
+    """returns dy, dres (masked dz, for the skip connection), dgamma, dbeta."""
+    M, Cp = y.shape
+    nblk = min(2048, (M + 63) // 64)
+    partials = empty((nblk, 2, Cp), f32, y)
+    H.bn_bwd_reduce(dz, y, z, sv.mean, sv.rstd, relu, partials, nblk, M, Cp)
+    dgamma, dbeta = empty((sv.C,), f32, y), empty((sv.C,), f32, y)
+    coef = empty((3, Cp), f32, y)
+    H.bn_bwd_finalize(partials, nblk, sv.count, sv.C, Cp, gamma, sv.rstd, dgamma, dbeta, coef)
+    dy = empty(y.shape, bf16, y)
+    dres = empty(y.shape, bf16, y) if want_dres else None
+    H.bn_bwd_apply(dz, y, z, sv.mean, sv.rstd, coef, relu, dy, dres, M, Cp)
+    return dy, dres, dgamma, dbeta
+
+
+# ---- Linear (dense GEMM) ------------------------------------------------------------------------------
+def prep_linear(w, need_dgrad=True):
+    """w fp32 [N][K] -> (bf16 [N][Kp], bf16 transposed [K][Np]) with Kp, Np multiples of 16."""
+    N, K = w.shape
+    Kp, Np = cpad(K), cpad(N)
+    wf = empty((N, Kp), bf16, w)
+    H.cast_pad_2d(w, wf, N, K, K, N, Kp)
+    wt = None
+    if need_dgrad:
+        wt = empty((K, Np), bf16, w)
+        H.cast_pad_2d(w, wt, K, N, K, K, Np, transpose=True)
+    return wf, wt
+
+
+def linear_fwd(x, M, wf, N, *, bias=None, act=H.ACT_NONE, residual=None, pre=None, out=None, out_f32=False):
+    """x bf16 [M][Kp] -> y [M][Np]."""
+    Kp = wf.shape[1]
+    Np = cpad(N)
+    y = out if out is not None else empty((M, Np), f32 if out_f32 else bf16, x)
+    H.igemm(x, wf, y, M, N, Kp, H.gather_dense(x.shape[1]), Kp, Np, b_rows=N, bias=bias, act=act, residual=residual,
+            ldr=Np, Cpre=pre)
+    return y
+
+
+def linear_dgrad(dy, M, wt, K, *, residual=None):
+    """dx [M][Kp] = dy [M][Np] @ W ; wt is the transposed operand [K][Np]."""
+    Np = wt.shape[1]
+    Kp = cpad(K)
+    dx = empty((M, Kp), bf16, dy)
+    H.igemm(dy, wt, dx, M, K, Np, H.gather_dense(dy.shape[1]), Np, Kp, b_rows=K, residual=residual, ldr=Kp)
+    return dx
+
+
+def linear_wgrad(x, dy, M, N, K, *, want_bias=True):
+    """dW fp32 [N][K], db fp32 [N] from x [M][Kp], dy [M][Np]."""
+    Kp, Np = x.shape[1], dy.shape[1]
+    gw = zeros((N, Kp), f32, x)
+    H.wgrad(x, dy, gw, M, N, Kp, H.gather_dense(Kp), Np, Kp)
+    if Kp != K:
+        dw = empty((N, K), f32, x)
+        H.copy_2d_f32(gw, Kp, dw, K, N, K)
+    else:
+        dw = gw
+    db = None
+    if want_bias:
+        db = empty((N,), f32, x)
+        H.colsum_bf16(dy, M, N, Np, db)
+    return dw, db
+
+
+# ---- LayerNorm ---------------------------------------------------------------------------------------
+def layernorm_fwd(x, ln, eps=1e-5):
+    rows, D = x.shape
+    y = empty(x.shape, bf16, x)
+    mean, rstd = empty((rows,), f32, x), empty((rows,), f32, x)
+    H.layernorm_fwd(x, ln.weight, ln.bias, eps, y, mean, rstd, rows, D)
+    return y, (mean, rstd)
+
+
+def layernorm_bwd(dy, x, ln, saved):
+    rows, D = x.shape
+    dx = empty(x.shape, bf16, x)
+    dg, db = zeros((D,), f32, x), zeros((D,), f32, x)
+    H.layernorm_bwd(dy, x, ln.weight, saved[0], saved[1], dx, dg, db, rows, D)
+    return dx, dg, db

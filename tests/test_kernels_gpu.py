@@ -1,0 +1,489 @@
+"""GPU parity of every HIP kernel (through the C ABI) against plain fp32 PyTorch on the CPU.
+
+Inputs are rounded to bf16 first so both sides see identical operands; tolerances below are
+for bf16 outputs of fp32-accumulated contractions (rel 2^-8 per rounding)."""
+import math
+import os
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from peppa_amd import hip as H
+from peppa_amd import layers as L
+
+DEV = "cuda"
+
+
+def rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def to_cl(x, cp):
+    """(B,C,T,H,W) fp32 -> channels-last bf16 [B*T*H*W][cp] on the GPU."""
+    B, C = x.shape[:2]
+    y = x.permute(0, 2, 3, 4, 1).reshape(-1, C)
+    out = torch.zeros(y.shape[0], cp)
+    out[:, :C] = y
+    return out.to(torch.bfloat16).to(DEV)
+
+
+def from_cl(y, B, thw, C):
+    return y.float().cpu()[:, :C].reshape(B, *thw, C).permute(0, 4, 1, 2, 3)
+
+
+def close(a, b, rtol=2e-2, atol=None, name=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    scale = b.abs().max().item() + 1e-12
+    atol = atol if atol is not None else 1e-2 * scale
+    assert a.shape == b.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    assert torch.isfinite(a).all(), f"{name}: non-finite output"
+    err = (a - b).abs().max().item()
+    assert err <= atol + rtol * scale, f"{name}: max err {err:.4g} vs scale {scale:.4g}"
+    cos = F.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+    assert cos > 0.9995, f"{name}: cosine {cos}"
+
+
+CONV_CASES = [
+    # Ci, Co, k, s, p, B, T, H, W
+    (64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), 2, 3, 10, 12),
+    (144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), 2, 5, 6, 7),
+    (64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), 2, 3, 10, 12),
+    (230, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), 2, 6, 5, 5),
+    (64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0), 2, 4, 8, 8),
+    (45, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), 1, 4, 9, 9),
+    (32, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1, 4, 6, 6),
+    (32, 40, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, 5, 7, 9),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_fwd_dgrad_wgrad(case):
+    Ci, Co, k, s, p, B, T, Hh, W = case
+    g = torch.Generator().manual_seed(Ci * 7 + Co)
+    x = rb(torch.randn(B, Ci, T, Hh, W, generator=g))
+    w = rb(torch.randn(Co, Ci, *k, generator=g) / math.sqrt(Ci * k[0] * k[1] * k[2]))
+    x.requires_grad_(); w.requires_grad_()
+    y_ref = F.conv3d(x, w, stride=s, padding=p)
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    xc = to_cl(x.detach(), geom.in_cstride)
+    wf, wd = L.prep_conv_weights(w.detach().to(DEV).contiguous(), geom)
+    y, partials = L.conv_fwd(xc, geom, wf, stats=True)
+    torch.cuda.synchronize()
+    close(from_cl(y, B, geom.out_thw, Co), y_ref, name="conv fwd")
+    assert (y.float().cpu()[:, Co:] == 0).all(), "padded output channels must be zero"
+    yf = y.float().cpu()
+    ps = partials.cpu().sum(0)
+    close(ps[0][:Co], yf.sum(0)[:Co], atol=2e-2 * yf.abs().sum(0).max().item(), name="colstats sum")
+    close(ps[1][:Co], (yf * yf).sum(0)[:Co], name="colstats sumsq")
+
+    dyc = to_cl(dy, geom.out_cstride)
+    dx = L.conv_dgrad(dyc, geom, wd)
+    dw = L.conv_wgrad(xc, dyc, geom, w.shape)
+    torch.cuda.synchronize()
+    close(from_cl(dx, B, (T, Hh, W), Ci), x.grad, name="conv dgrad")
+    close(dw, w.grad, name="conv wgrad")
+
+
+def test_stem_conv_cin3():
+    g = torch.Generator().manual_seed(1)
+    B, T, Hh, W = 2, 3, 20, 24
+    x = torch.rand(B, 3, T, Hh, W, generator=g)
+    mean, std = (0.62745821, 0.66273642, 0.66865104), (0.24167268, 0.20884572, 0.27490067)
+    xn = (x - torch.tensor(mean).view(1, 3, 1, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1, 1)
+    w = rb(torch.randn(45, 3, 1, 7, 7, generator=g) / 12).requires_grad_()
+    xr = rb(xn)
+    y_ref = F.conv3d(xr, w, stride=(1, 2, 2), padding=(0, 3, 3))
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    geom = L.ConvGeom(B, (T, Hh, W), 3, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3), in_cstride=8, cg_in=8)
+    xc = torch.empty(B * T * Hh * W, 8, dtype=torch.bfloat16, device=DEV)
+    H.video_normalize_ndhwc(x.to(DEV), xc, mean, std)
+    torch.cuda.synchronize()
+    close(xc.float().cpu()[:, :3].reshape(B, T, Hh, W, 3).permute(0, 4, 1, 2, 3), xn, name="video normalize")
+    assert (xc.float().cpu()[:, 3:] == 0).all()
+    wf, _ = L.prep_conv_weights(w.detach().to(DEV), geom, need_dgrad=False)
+    y, _ = L.conv_fwd(xc, geom, wf, stats=True)
+    dw = L.conv_wgrad(xc, to_cl(dy, geom.out_cstride), geom, w.shape)
+    torch.cuda.synchronize()
+    close(from_cl(y, B, geom.out_thw, 45), y_ref, name="stem fwd")
+    close(dw, w.grad, name="stem wgrad")
+
+
+@pytest.mark.parametrize("k,s,T", [(3, 2, 41), (2, 2, 30)])
+def test_conv1d_stack_layer(k, s, T):
+    """wav2vec2 feature-extractor convs: Conv1d(512,512,k,s) as a strided GEMM + GELU epilogue."""
+    g = torch.Generator().manual_seed(k)
+    B, C = 3, 512
+    x = rb(torch.randn(B, C, T, generator=g)).requires_grad_()
+    w = rb(torch.randn(C, C, k, generator=g) / math.sqrt(C * k)).requires_grad_()
+    u_ref = F.conv1d(x, w, stride=s)
+    y_ref = F.gelu(u_ref)
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    geom = L.ConvGeom(B, (T, 1, 1), C, C, (k, 1, 1), (s, 1, 1), (0, 0, 0))
+    xc = x.detach().permute(0, 2, 1).reshape(-1, C).to(torch.bfloat16).to(DEV).contiguous()
+    wf, wd = L.prep_conv_weights(w.detach().to(DEV), geom)
+    pre = torch.empty(geom.M, C, dtype=torch.bfloat16, device=DEV)
+    y, _ = L.conv_fwd(xc, geom, wf, act=H.ACT_GELU, pre=pre)
+    torch.cuda.synchronize()
+    To = geom.To
+    close(y.float().cpu().reshape(B, To, C).permute(0, 2, 1), y_ref, name="conv1d+gelu")
+    close(pre.float().cpu().reshape(B, To, C).permute(0, 2, 1), u_ref, name="conv1d pre-activation")
+    dyc = dy.permute(0, 2, 1).reshape(-1, C).to(torch.bfloat16).to(DEV).contiguous()
+    du = torch.empty_like(dyc)
+    H.gelu_bwd(dyc, pre, du)
+    dx = L.conv_dgrad(du, geom, wd)
+    dw = L.conv_wgrad(xc, du, geom, w.shape)
+    torch.cuda.synchronize()
+    close(dx.float().cpu().reshape(B, T, C).permute(0, 2, 1), x.grad, name="conv1d dgrad")
+    close(dw, w.grad, name="conv1d wgrad")
+
+
+def test_grouped_posconv():
+    g = torch.Generator().manual_seed(9)
+    B, T, C, G, K = 2, 37, 768, 16, 128
+    x = rb(torch.randn(B, C, T, generator=g)).requires_grad_()
+    w = rb(torch.randn(C, C // G, K, generator=g) / math.sqrt(K * C // G)).requires_grad_()
+    bias = torch.randn(C, generator=g)
+    y_ref = F.conv1d(x, w, bias, padding=K // 2, groups=G)[..., :-1]
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    geom = L.ConvGeom(B, (T, 1, 1), C, C, (K, 1, 1), (1, 1, 1), (K // 2, 0, 0), groups=G, To=T)
+    xc = x.detach().permute(0, 2, 1).reshape(-1, C).to(torch.bfloat16).to(DEV).contiguous()
+    wf, wd = L.prep_conv_weights(w.detach().to(DEV), geom)
+    y, _ = L.conv_fwd(xc, geom, wf, bias=bias.to(DEV))
+    dyc = dy.permute(0, 2, 1).reshape(-1, C).to(torch.bfloat16).to(DEV).contiguous()
+    dx = L.conv_dgrad(dyc, geom, wd)
+    dw = L.conv_wgrad(xc, dyc, geom, w.shape)
+    torch.cuda.synchronize()
+    close(y.float().cpu().reshape(B, T, C).permute(0, 2, 1), y_ref, name="posconv fwd")
+    close(dx.float().cpu().reshape(B, T, C).permute(0, 2, 1), x.grad, name="posconv dgrad")
+    close(dw, w.grad, name="posconv wgrad")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 768, 512), (257, 28, 768), (64, 3072, 768), (1000, 768, 3072), (5, 512, 28)])
+def test_linear_fwd_bwd(M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    x = rb(torch.randn(M, K, generator=g)).requires_grad_()
+    w = rb(torch.randn(N, K, generator=g) / math.sqrt(K)).requires_grad_()
+    b = torch.randn(N, generator=g).requires_grad_()
+    res = rb(torch.randn(M, N, generator=g))
+    y_ref = F.linear(x, w, b) + res
+    dy = rb(torch.randn(M, N, generator=g))
+    y_ref.backward(dy)
+    Kp, Np = L.cpad(K), L.cpad(N)
+
+    def padded(t, cols):
+        o = torch.zeros(t.shape[0], cols)
+        o[:, :t.shape[1]] = t
+        return o.to(torch.bfloat16).to(DEV)
+    xc, rc, dyc = padded(x.detach(), Kp), padded(res, Np), padded(dy, Np)
+    wf, wt = L.prep_linear(w.detach().to(DEV))
+    bd = b.detach().to(DEV)
+    y = L.linear_fwd(xc, M, wf, N, bias=bd, residual=rc)
+    dx = L.linear_dgrad(dyc, M, wt, K)
+    dw, db = L.linear_wgrad(xc, dyc, M, N, K)
+    torch.cuda.synchronize()
+    close(y[:, :N], y_ref, name="linear fwd")
+    close(dx[:, :K], x.grad, name="linear dgrad")
+    close(dw, w.grad, name="linear wgrad")
+    close(db, b.grad, name="linear bias grad")
+    y32 = L.linear_fwd(xc, M, wf, N, bias=bd, out_f32=True)
+    torch.cuda.synchronize()
+    close(y32[:, :N], y_ref - res, rtol=2e-3, atol=2e-3 * y_ref.abs().max().item(), name="linear fp32 out")
+
+
+def test_batched_attention_gemms():
+    """Q K^T per (batch, head) with strided operands, softmax, and the per-head transpose."""
+    g = torch.Generator().manual_seed(4)
+    B, Hn, T, Dh = 2, 12, 50, 64
+    D = Hn * Dh
+    q = rb(torch.randn(B * T, D, generator=g))
+    k = rb(torch.randn(B * T, D, generator=g))
+    ref = torch.einsum("bthd,bshd->bhts", q.view(B, T, Hn, Dh), k.view(B, T, Hn, Dh))
+    Tp = L.cpad(T)
+    S = torch.zeros(B * Hn, T, Tp, dtype=torch.float32, device=DEV)
+    H.igemm(q.to(torch.bfloat16).to(DEV), k.to(torch.bfloat16).to(DEV), S, T, T, Dh, H.gather_dense(D), D, Tp,
+            nbatch=B * Hn, inner=Hn, a_s=(T * D, Dh), b_s=(T * D, Dh), c_s=(Hn * T * Tp, T * Tp))
+    torch.cuda.synchronize()
+    close(S.cpu()[:, :, :T].reshape(B, Hn, T, T), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item(), name="QK^T")
+    P = torch.empty(B * Hn, T, Tp, dtype=torch.bfloat16, device=DEV)
+    H.softmax_fwd(S, Tp, P, Tp, B * Hn, T, 0.125)
+    Sr = (S.cpu()[:, :, :T] * 0.125).requires_grad_()
+    Pr = torch.softmax(Sr, dim=-1)
+    dP = torch.randn(B * Hn, T, Tp, generator=g)
+    Pr.backward(dP[:, :, :T])
+    dS = torch.empty_like(P)
+    H.softmax_bwd(dP.to(DEV), Tp, P, Tp, dS, B * Hn, T, 0.125)
+    torch.cuda.synchronize()
+    close(P[:, :, :T], Pr, name="softmax fwd")
+    assert (P.float().cpu()[:, :, T:] == 0).all()
+    close(dS[:, :, :T], Sr.grad * 0.125, name="softmax bwd")
+    Vt = torch.empty(B * Hn, Dh, Tp, dtype=torch.bfloat16, device=DEV)
+    kd = k.to(torch.bfloat16).to(DEV)
+    H.transpose_bf16(kd, T * D, D, Vt, Hn * Dh * Tp, Tp, B * Hn, T, Dh, inner=Hn, in_s1=Dh, out_s1=Dh * Tp)
+    torch.cuda.synchronize()
+    ref_t = k.view(B, T, Hn, Dh).permute(0, 2, 3, 1).reshape(B * Hn, Dh, T)
+    assert torch.equal(Vt.float().cpu()[:, :, :T], ref_t)
+    assert (Vt.float().cpu()[:, :, T:] == 0).all()
+
+
+class _BNP:
+    pass
+
+
+def test_batchnorm_fwd_bwd():
+    g = torch.Generator().manual_seed(2)
+    B, C, T, Hh, W = 2, 45, 3, 5, 6
+    Cp = L.cpad(C)
+    y = rb(torch.randn(B, C, T, Hh, W, generator=g) * 2 + 0.5).requires_grad_()
+    res = rb(torch.randn(B, C, T, Hh, W, generator=g))
+    bn = torch.nn.BatchNorm3d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    z_ref = F.relu(bn(y) + res)
+    dz = rb(torch.randn(z_ref.shape, generator=g))
+    z_ref.backward(dz)
+    P = _BNP()
+    P.weight, P.bias = bn.weight.detach().clone().to(DEV), bn.bias.detach().clone().to(DEV)
+    P.running_mean, P.running_var = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    yc = to_cl(y.detach(), Cp)
+    M = yc.shape[0]
+    nblk = 3
+    partials = torch.empty(nblk, 2, Cp, device=DEV)
+    H.colstats_bf16(yc, M, Cp, partials, nblk)
+    z, sv = L.bn_fwd(yc, partials, nblk, M, P, relu=True, residual=to_cl(res, Cp))
+    dy, dres, dg, db = L.bn_bwd(to_cl(dz, Cp), yc, z, sv, P.weight, relu=True, want_dres=True)
+    torch.cuda.synchronize()
+    thw = (T, Hh, W)
+    close(from_cl(z, B, thw, C), z_ref, name="bn fwd")
+    close(from_cl(dy, B, thw, C), y.grad, name="bn dx")
+    close(dg, bn.weight.grad, name="bn dgamma")
+    close(db, bn.bias.grad, name="bn dbeta")
+    mask = (z_ref.detach() > 0).float()
+    close(from_cl(dres, B, thw, C), dz * mask, name="bn dres")
+    close(P.running_mean, bn.running_mean, rtol=1e-3, atol=1e-3, name="running mean")
+    close(P.running_var, bn.running_var, rtol=1e-3, atol=1e-3, name="running var")
+    assert (z.float().cpu()[:, C:] == 0).all()
+
+
+def test_layernorm_gelu_add():
+    g = torch.Generator().manual_seed(3)
+    for D in (512, 768):
+        rows = 37
+        x = rb(torch.randn(rows, D, generator=g) * 1.5 + 0.3).requires_grad_()
+        ln = torch.nn.LayerNorm(D)
+        with torch.no_grad():
+            ln.weight.copy_(torch.rand(D, generator=g) + 0.5)
+            ln.bias.copy_(torch.randn(D, generator=g) * 0.1)
+        y_ref = ln(x)
+        dy = rb(torch.randn(rows, D, generator=g))
+        y_ref.backward(dy)
+        lnd = torch.nn.LayerNorm(D).to(DEV)
+        lnd.load_state_dict(ln.state_dict())
+        xd = x.detach().to(torch.bfloat16).to(DEV)
+        y, saved = L.layernorm_fwd(xd, lnd)
+        dx, dg, db = L.layernorm_bwd(dy.to(torch.bfloat16).to(DEV), xd, lnd, saved)
+        torch.cuda.synchronize()
+        close(y, y_ref, name="ln fwd")
+        close(dx, x.grad, name="ln dx")
+        close(dg, ln.weight.grad, name="ln dgamma")
+        close(db, ln.bias.grad, name="ln dbeta")
+    x = rb(torch.randn(64, 40, generator=g) * 2).requires_grad_()
+    y_ref = F.gelu(x)
+    dy = rb(torch.randn(64, 40, generator=g))
+    y_ref.backward(dy)
+    xd = x.detach().to(torch.bfloat16).to(DEV)
+    y, dx, s = torch.empty_like(xd), torch.empty_like(xd), torch.empty_like(xd)
+    H.gelu_fwd(xd, y)
+    H.gelu_bwd(dy.to(torch.bfloat16).to(DEV), xd, dx)
+    H.add_bf16(xd, y, s)
+    torch.cuda.synchronize()
+    close(y, y_ref, name="gelu fwd")
+    close(dx, x.grad, name="gelu bwd")
+    close(s, x.detach() + rb(y_ref.detach()), name="add")
+
+
+def test_conv0_groupnorm_gelu():
+    g = torch.Generator().manual_seed(5)
+    B, Lw = 2, 1205
+    T0 = (Lw - 10) // 5 + 1
+    wave = 0.1 * torch.randn(B, Lw, generator=g)
+    conv = torch.nn.Conv1d(1, 512, 10, 5, bias=False)
+    gn = torch.nn.GroupNorm(512, 512)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(512, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(512, generator=g) * 0.1)
+    y_ref = F.gelu(gn(conv(wave.unsqueeze(1))))
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    wv, w = wave.to(DEV), conv.weight.detach().reshape(512, 10).to(DEV).contiguous()
+    gam, bet = gn.weight.detach().to(DEV), gn.bias.detach().to(DEV)
+    stats = torch.zeros(B, 512, 2, device=DEV)
+    out = torch.empty(B * T0, 512, dtype=torch.bfloat16, device=DEV)
+    H.conv0_stats(wv, B, Lw, T0, w, stats)
+    H.conv0_apply(wv, B, Lw, T0, w, stats, gam, bet, 1e-5, out)
+    dout = dy.permute(0, 2, 1).reshape(-1, 512).to(torch.bfloat16).to(DEV).contiguous()
+    red = torch.zeros(B, 512, 2, device=DEV)
+    dw, dgam, dbet = torch.zeros(512, 10, device=DEV), torch.zeros(512, device=DEV), torch.zeros(512, device=DEV)
+    H.conv0_bwd_reduce(wv, B, Lw, T0, w, stats, gam, bet, 1e-5, dout, red)
+    H.conv0_bwd_apply(wv, B, Lw, T0, w, stats, gam, bet, 1e-5, dout, red, dw, dgam, dbet)
+    torch.cuda.synchronize()
+    close(out.float().cpu().reshape(B, T0, 512).permute(0, 2, 1), y_ref, name="conv0 fwd")
+    close(dw, conv.weight.grad.reshape(512, 10), name="conv0 dw")
+    close(dgam, gn.weight.grad, name="conv0 dgamma")
+    close(dbet, gn.bias.grad, name="conv0 dbeta")
+
+
+def test_weightnorm():
+    g = torch.Generator().manual_seed(6)
+    Co, Ci, K = 32, 8, 16
+    v = torch.randn(Co, Ci, K, generator=g).requires_grad_()
+    gg = (torch.rand(1, 1, K, generator=g) + 0.5).requires_grad_()
+    w_ref = gg * v / v.norm(2, dim=(0, 1), keepdim=True)
+    dw = torch.randn(Co, Ci, K, generator=g)
+    w_ref.backward(dw)
+    vd, gd = v.detach().to(DEV), gg.detach().reshape(K).to(DEV)
+    norm = torch.empty(K, device=DEV)
+    out = torch.empty(Co, K, Ci, dtype=torch.bfloat16, device=DEV)
+    H.weightnorm_fwd(vd, gd, Co, Ci, K, norm, out)
+    dwt = dw.permute(0, 2, 1).contiguous().to(DEV)
+    dv, dg, ws = torch.empty_like(vd), torch.empty(K, device=DEV), torch.empty(K, device=DEV)
+    H.weightnorm_bwd(dwt, vd, gd, norm, Co, Ci, K, dv, dg, ws)
+    torch.cuda.synchronize()
+    close(out.float().cpu().permute(0, 2, 1), w_ref, name="weightnorm fwd")
+    close(dv, v.grad, rtol=1e-4, atol=1e-5, name="weightnorm dv")
+    close(dg, gg.grad.reshape(K), rtol=1e-4, atol=1e-5, name="weightnorm dg")
+
+
+@pytest.mark.parametrize("T,Fd,proj", [(49, 28, True), (2, 512, True), (5, 40, False)])
+def test_attnpool_head(T, Fd, proj):
+    from oracle import model as O
+    g = torch.Generator().manual_seed(T)
+    B, Hd = 4, 128
+    E = 512 if proj else Fd
+    torch.manual_seed(T)
+    att = O.Attention(Fd, Hd)
+    lin = torch.nn.Linear(Fd, E) if proj else None
+    x = torch.randn(B, T, Fd, generator=g).requires_grad_()
+    pooled = att(x)
+    out_ref = F.normalize(lin(pooled) if proj else pooled, p=2, dim=1)
+    dout = torch.randn(B, E, generator=g)
+    out_ref.backward(dout)
+
+    def d(t):
+        return None if t is None else t.detach().to(DEV).contiguous()
+
+    def e(*s):
+        return torch.empty(*s, device=DEV)
+    W1, b1, W2, b2 = d(att.hidden.weight), d(att.hidden.bias), d(att.out.weight), d(att.out.bias)
+    Wp, bp = (d(lin.weight), d(lin.bias)) if proj else (None, None)
+    xd = d(x)
+    hid, alpha, pl, pre, out = e(B, T, Hd), e(B, T, Fd), e(B, Fd), e(B, E), e(B, E)
+    H.attnpool_fwd(xd, B, T, Fd, Hd, E, W1, b1, W2, b2, Wp, bp, hid, alpha, pl, pre, out)
+    dx, dW1, db1, dW2, db2 = e(B, T, Fd), e(Hd, Fd), e(Hd), e(Fd, Hd), e(Fd)
+    dWp, dbp = (e(E, Fd), e(E)) if proj else (None, None)
+    ws = e(H.attnpool_ws_floats(B, T, Fd, Hd, E))
+    H.attnpool_bwd(d(dout), xd, B, T, Fd, Hd, E, W1, W2, Wp, hid, alpha, pl, pre, out, dx, dW1, db1, dW2, db2, dWp,
+                   dbp, ws)
+    torch.cuda.synchronize()
+    tol = dict(rtol=1e-4, atol=1e-5)
+    close(out, out_ref, name="head out", **tol)
+    close(dx, x.grad, name="head dx", **tol)
+    close(dW1, att.hidden.weight.grad, name="dW1", **tol)
+    close(db1, att.hidden.bias.grad, name="db1", **tol)
+    close(dW2, att.out.weight.grad, name="dW2", **tol)
+    close(db2, att.out.bias.grad, name="db2", **tol)
+    if proj:
+        close(dWp, lin.weight.grad, name="dWp", **tol)
+        close(dbp, lin.bias.grad, name="dbp", **tol)
+
+
+def test_spatial_mean():
+    g = torch.Generator().manual_seed(8)
+    B, T, HW, C = 2, 3, 49, 512
+    x = rb(torch.randn(B, T, HW, C, generator=g))
+    xd = x.to(torch.bfloat16).to(DEV)
+    out = torch.empty(B, T, C, device=DEV)
+    H.spatial_mean_fwd(xd, out, B, T, HW, C, C)
+    dout = torch.randn(B, T, C, generator=g)
+    dx = torch.empty_like(xd)
+    H.spatial_mean_bwd(dout.to(DEV), dx, B, T, HW, C, C)
+    torch.cuda.synchronize()
+    close(out, x.mean(2), rtol=1e-5, atol=1e-6, name="spatial mean")
+    close(dx, (dout / HW).unsqueeze(2).expand(B, T, HW, C), name="spatial mean bwd")
+
+
+def test_triplet_loss_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "ref_loss.npz"))
+
+    def run(V, A, margin=0.2, dloss=1.0):
+        V, A = V.to(DEV).contiguous(), A.to(DEV).contiguous()
+        N, D = V.shape
+        ws = torch.empty(H.triplet_workspace_bytes(N, D) // 4, device=DEV)
+        loss = torch.empty(1, device=DEV)
+        H.triplet_loss_fwd(V, A, margin, loss, ws)
+        dV, dA = torch.empty_like(V), torch.empty_like(A)
+        H.triplet_loss_bwd(V, A, torch.tensor([dloss], device=DEV), ws, dV, dA)
+        torch.cuda.synchronize()
+        return loss.item(), dV.cpu(), dA.cpu()
+
+    for n in (4, 64):
+        loss, dV, dA = run(torch.tensor(d[f"V_{n}"]), torch.tensor(d[f"A_{n}"]))
+        assert abs(loss - float(d[f"loss_{n}"])) < 1e-6
+        np.testing.assert_allclose(dV.numpy(), d[f"dV_{n}"], atol=2e-7)
+        np.testing.assert_allclose(dA.numpy(), d[f"dA_{n}"], atol=2e-7)
+    gg = torch.Generator().manual_seed(0)
+    V = F.normalize(torch.randn(512, 512, generator=gg))
+    A = F.normalize(torch.randn(512, 512, generator=gg))
+    loss, dV, dA = run(V, A)
+    assert abs(loss - float(d["loss_512"])) < 1e-6
+    assert abs(dV.norm().item() - float(d["dVnorm_512"])) < 1e-6
+    np.testing.assert_allclose(dV[:4].numpy(), d["dV_512_head"], atol=2e-7)
+    np.testing.assert_allclose(dA[-4:].numpy(), d["dA_512_tail"], atol=2e-7)
+    loss, dV, dA = run(torch.tensor(d["rawV"]), torch.tensor(d["rawA"]))
+    assert abs(loss - float(d["raw_loss"])) < 1e-6
+    np.testing.assert_allclose(dV.numpy(), d["raw_dV"], atol=2e-7)
+    np.testing.assert_allclose(dA.numpy(), d["raw_dA"], atol=2e-7)
+    for m, ref in zip(d["margins"], d["margin_losses"]):
+        loss, _, _ = run(torch.tensor(d["V_4"]), torch.tensor(d["A_4"]), margin=float(m))
+        assert abs(loss - ref) < 1e-6
+    loss, dV2, _ = run(torch.tensor(d["V_64"]), torch.tensor(d["A_64"]), dloss=8.0)
+    np.testing.assert_allclose(dV2.numpy(), 8.0 * d["dV_64"], atol=2e-6)
+
+
+def test_bertadam_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "ref_bertadam.npz"))
+    ps = [torch.tensor(d[f"p0_{i}"]).to(DEV) for i in range(5)]
+    gs = [torch.zeros_like(p) for p in ps]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    tl, keep = H.make_tensor_list(ps, gs, ms, vs, DEV)
+    chunk = 16
+    ct, co = [], []
+    for i, p in enumerate(ps):
+        for off in range(0, p.numel(), chunk):
+            ct.append(i)
+            co.append(off)
+    ctd = torch.tensor(ct, dtype=torch.int32, device=DEV)
+    cod = torch.tensor(co, dtype=torch.int64, device=DEV)
+    norms = torch.empty(5, device=DEV)
+    from oracle.model import warmup_linear
+    for step in range(6):
+        for i in range(5):
+            gs[i].copy_(torch.tensor(d[f"g{step}_{i}"]))
+        lr = 1e-3 * warmup_linear(step / 8, 0.25)
+        H.bertadam_step(tl, ctd, cod, len(ct), chunk, norms, lr, 0.9, 0.999, 1e-6, 0.01, 1.0)
+        torch.cuda.synchronize()
+        for i in range(5):
+            np.testing.assert_allclose(ps[i].cpu().numpy(), d[f"p{step + 1}_{i}"], atol=3e-7)
+    for i in range(5):
+        np.testing.assert_allclose(ms[i].cpu().numpy(), d[f"m_{i}"], atol=1e-6)
+        np.testing.assert_allclose(vs[i].cpu().numpy(), d[f"v_{i}"], rtol=1e-5, atol=1e-9)
