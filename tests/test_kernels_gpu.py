@@ -42,8 +42,9 @@ def close(a, b, rtol=2e-2, atol=None, name=""):
     assert torch.isfinite(a).all(), f"{name}: non-finite output"
     err = (a - b).abs().max().item()
     assert err <= atol + rtol * scale, f"{name}: max err {err:.4g} vs scale {scale:.4g}"
-    cos = F.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
-    assert cos > 0.9995, f"{name}: cosine {cos}"
+    if scale > 1e-6:  # cosine is meaningless for an (analytically) zero reference such as db2
+        cos = F.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+        assert cos > 0.9995, f"{name}: cosine {cos}"
 
 
 CONV_CASES = [
@@ -483,7 +484,7 @@ def test_bertadam_golden(golden_dir):
         H.bertadam_step(tl, ctd, cod, len(ct), chunk, norms, lr, 0.9, 0.999, 1e-6, 0.01, 1.0)
         torch.cuda.synchronize()
         for i in range(5):
-            np.testing.assert_allclose(ps[i].cpu().numpy(), d[f"p{step + 1}_{i}"], atol=3e-7)
+            np.testing.assert_allclose(ps[i].cpu().numpy(), d[f"p{step + 1}_{i}"], rtol=2e-6, atol=3e-7)  # few fp32 ulps (FMA contraction)
     for i in range(5):
         np.testing.assert_allclose(ms[i].cpu().numpy(), d[f"m_{i}"], atol=1e-6)
         np.testing.assert_allclose(vs[i].cpu().numpy(), d[f"v_{i}"], rtol=1e-5, atol=1e-9)
