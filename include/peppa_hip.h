@@ -87,16 +87,19 @@ int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, void* out, int
                         int transpose_io, int flip, float scale, pp_stream_t s);
 /* g [Co][taps][cg] fp32 (pp_wgrad layout) -> dw [Co][Ci][taps] fp32, dw = g (beta=0) or += */
 int pp_unprep_conv_grad(const float* g, int Co, int Ci, int taps, int cg, float* dw, pp_stream_t s);
-/* generic 2-D fp32 -> bf16 copy with padding / transpose: out[r][c] = in[r][c] (or in[c][r]) */
-int pp_cast_pad_2d(const float* in, int rows, int cols, int ld_in, void* out, int rows_out, int ld_out,
-                   int transpose, pp_stream_t s);
+/* generic 2-D fp32 -> bf16 copy with padding / transpose: out[r*ld_out + c] = in[r][c] (or in[c][r]) for
+ * r < rows_out, c < cols_out; zero outside rows x cols */
+int pp_cast_pad_2d(const float* in, int rows, int cols, int ld_in, void* out, int rows_out, int cols_out,
+                   int ld_out, int transpose, pp_stream_t s);
 int pp_cast_f32_to_bf16(const float* in, void* out, long long n, pp_stream_t s);
 int pp_cast_bf16_to_f32(const void* in, float* out, long long n, pp_stream_t s);
 /* strided fp32 2-D copy: out[r*ld_out + c] = in[r*ld_in + c] */
 int pp_copy_2d_f32(const float* in, int ld_in, float* out, int ld_out, int rows, int cols, pp_stream_t s);
-/* batched bf16 transpose: in [nb][R][ld_in] (cols C) -> out [nb][C][ld_out] (cols R, zero padded) */
+/* batched bf16 transpose: in [nb][R][ld_in] (cols C) -> out [nb][C][ld_out]; columns R..r_pad-1 of each
+ * output row are zero-filled (r_pad = 0 means ld_out) */
 int pp_transpose_bf16(const void* in, long long in_bs, int ld_in, void* out, long long out_bs, int ld_out,
-                      int nb, int R, int C, int inner, long long in_s1, long long out_s1, pp_stream_t s);
+                      int nb, int R, int C, int inner, long long in_s1, long long out_s1, int r_pad,
+                      pp_stream_t s);
 int pp_fill_f32(float* p, float v, long long n, pp_stream_t s);
 
 /* ---- video input transform: pig/models.py:327-342 build_transform + layout change ------
@@ -111,6 +114,10 @@ int pp_bn_finalize(const float* partials, int nblk, int ldstat, long long count,
                    const float* gamma, const float* beta, float eps, float momentum,
                    float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
                    float* shift, pp_stream_t s);
+/* eval mode: scale/shift from the running statistics */
+int pp_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int C, int Cp, float* scale, float* shift,
+                      pp_stream_t s);
 /* stats straight from a bf16 tensor [M][Cp] (used when no igemm epilogue produced them) */
 int pp_colstats_bf16(const void* y, long long M, int Cp, float* partials, int nblk, pp_stream_t s);
 /* z = relu?(y*scale+shift (+res)) */
@@ -178,11 +185,11 @@ int pp_spatial_mean_bwd(const float* dout, void* dx, int B, int T, int HW, int C
  * x fp32 [B][T][F]; W1 [Hd][F], b1 [Hd], W2 [F][Hd], b2 [F], Wp [E][F], bp [E] (Wp may be NULL)
  * saves alpha [B][T][F], hid [B][T][Hd], pooled [B][F], pre [B][E], out [B][E] */
 int pp_attnpool_fwd(const float* x, int B, int T, int F, int Hd, int E, const float* W1, const float* b1,
-                    const float* W2, const float* b2, const float* Wp, const float* bp, float* hid,
-                    float* alpha, float* pooled, float* pre, float* out, pp_stream_t s);
+                    const float* W2, const float* b2, const float* Wp, const float* bp, int normalize,
+                    float* hid, float* alpha, float* pooled, float* pre, float* out, pp_stream_t s);
 /* dW1..dbp and dx [B][T][F] are overwritten */
 int pp_attnpool_bwd(const float* dout, const float* x, int B, int T, int F, int Hd, int E, const float* W1,
-                    const float* W2, const float* Wp, const float* hid, const float* alpha,
+                    const float* W2, const float* Wp, int normalize, const float* hid, const float* alpha,
                     const float* pooled, const float* pre, const float* out, float* dx, float* dW1,
                     float* db1, float* dW2, float* db2, float* dWp, float* dbp,
                     float* ws /* pp_attnpool_ws_floats() floats */, pp_stream_t s);
@@ -197,6 +204,14 @@ int pp_triplet_loss_fwd(const float* V, const float* A, int N, int D, float marg
 /* dV, dA fp32 [N][D] = dloss * dL/dV, dL/dA (dloss read from device memory) */
 int pp_triplet_loss_bwd(const float* V, const float* A, int N, int D, const float* dloss, const void* ws,
                         float* dV, float* dA, pp_stream_t s);
+
+/* pig/loss.py:51-55 cosine_matrix(U, V): out [Nu][Nv]; ws (Nu+Nv)*D floats */
+int pp_cosine_matrix(const float* U, const float* V, int Nu, int Nv, int D, float* out, float* ws, pp_stream_t s);
+/* pig/loss.py:41-48 contrastive(M, margin) forward on a given similarity matrix; ws N*N+3N floats */
+int pp_contrastive_fwd(const float* S, int N, float margin, float* loss, float* ws, pp_stream_t s);
+/* pig/metrics.py:45-52 triplet_accuracy: a, p, n fp32 [M][D] -> out [M] ((sign(diff)+1)/2 or diff) */
+int pp_triplet_accuracy(const float* a, const float* p, const float* n, int M, int D, int discrete, float* out,
+                        pp_stream_t s);
 
 /* ---- pig/optimization.py:101-179 BertAdam.step (multi-tensor) --------------------------- */
 typedef struct pp_tensor_list {

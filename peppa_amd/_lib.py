@@ -54,15 +54,16 @@ SIGNATURES = {
     "pp_wgrad": [C.POINTER(WGradDesc), P],
     "pp_prep_conv_weight": [P, I, I, I, P, I, I, I, I, F, P],
     "pp_unprep_conv_grad": [P, I, I, I, I, P, P],
-    "pp_cast_pad_2d": [P, I, I, I, P, I, I, I, P],
+    "pp_cast_pad_2d": [P, I, I, I, P, I, I, I, I, P],
     "pp_cast_f32_to_bf16": [P, P, L, P],
     "pp_cast_bf16_to_f32": [P, P, L, P],
     "pp_copy_2d_f32": [P, I, P, I, I, I, P],
-    "pp_transpose_bf16": [P, L, I, P, L, I, I, I, I, I, L, L, P],
+    "pp_transpose_bf16": [P, L, I, P, L, I, I, I, I, I, L, L, I, P],
     "pp_fill_f32": [P, F, L, P],
     "pp_video_normalize_ndhwc": [P, P, I, I, I, I, C.POINTER(F), C.POINTER(F), P],
     "pp_bn_finalize": [P, I, I, L, I, I, P, P, F, F, P, P, P, P, P, P, P],
     "pp_colstats_bf16": [P, L, I, P, I, P],
+    "pp_bn_eval_affine": [P, P, P, P, F, I, I, P, P, P],
     "pp_bn_apply": [P, P, P, P, I, P, L, I, P],
     "pp_bn_bwd_reduce": [P, P, P, P, P, I, P, I, L, I, P],
     "pp_bn_bwd_finalize": [P, I, L, I, I, P, P, P, P, P, P],
@@ -83,12 +84,15 @@ SIGNATURES = {
     "pp_weightnorm_bwd": [P, P, P, P, I, I, I, P, P, P, P],
     "pp_spatial_mean_fwd": [P, P, I, I, I, I, I, P],
     "pp_spatial_mean_bwd": [P, P, I, I, I, I, I, P],
-    "pp_attnpool_fwd": [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
-    "pp_attnpool_bwd": [P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "pp_attnpool_fwd": [P, I, I, I, I, I, P, P, P, P, P, P, I, P, P, P, P, P, P],
+    "pp_attnpool_bwd": [P, P, I, I, I, I, I, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "pp_attnpool_ws_floats": [I, I, I, I, I],
     "pp_triplet_workspace_bytes": [I, I],
     "pp_triplet_loss_fwd": [P, P, I, I, F, P, P, Z, P],
     "pp_triplet_loss_bwd": [P, P, I, I, P, P, P, P, P],
+    "pp_cosine_matrix": [P, P, I, I, I, P, P, P],
+    "pp_contrastive_fwd": [P, I, F, P, P, P],
+    "pp_triplet_accuracy": [P, P, P, I, I, I, P, P],
     "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P],
 }
 _RESTYPE = {"pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z}

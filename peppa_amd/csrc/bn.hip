@@ -188,6 +188,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bfraw* __restri
   }
 }
 
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, int Cp, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  if (c < C) {
+    const float sc = gamma[c] * rsqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+  } else {
+    scale[c] = 0.f;
+    shift[c] = 0.f;
+  }
+}
+
 int stream_grid(long long nchunks) {
   long long b = (nchunks + 255) / 256;
   if (b > 4096) b = 4096;
@@ -256,6 +270,15 @@ extern "C" int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, con
   const long long nchunks = M * (Cp / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nchunks)), dim3(256), 0, (hipStream_t)s, (const bfraw*)dz,
                      (const bfraw*)y, (const bfraw*)z, mean, rstd, coef, relu, (bfraw*)dy, (bfraw*)dres, nchunks, Cp / 8, Cp);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                 float eps, int C, int Cp, float* scale, float* shift, pp_stream_t s) {
+  PP_CHECK_ARG(C > 0 && Cp >= C, "pp_bn_eval_affine: sizes");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((Cp + 255) / 256), dim3(256), 0, (hipStream_t)s, gamma, beta, running_mean,
+                     running_var, eps, C, Cp, scale, shift);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

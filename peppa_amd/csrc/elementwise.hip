@@ -70,12 +70,12 @@ __global__ void copy2d_kernel(const float* __restrict__ in, int ld_in, float* __
 
 // out[r][c] (rows_out x ld_out, zero padded) = in[r][c] or in[c][r]
 __global__ void cast_pad_2d_kernel(const float* __restrict__ in, int rows, int cols, int ld_in, bfraw* __restrict__ out,
-                                   int rows_out, int ld_out, int transpose) {
-  GSTRIDE(i, (long long)rows_out * ld_out) {
-    const int r = (int)(i / ld_out), c = (int)(i % ld_out);
+                                   int rows_out, int cols_out, int ld_out, int transpose) {
+  GSTRIDE(i, (long long)rows_out * cols_out) {
+    const int r = (int)(i / cols_out), c = (int)(i % cols_out);
     float v = 0.f;
     if (r < rows && c < cols) v = transpose ? in[(long long)c * ld_in + r] : in[(long long)r * ld_in + c];
-    out[i] = f2bf(v);
+    out[(long long)r * ld_out + c] = f2bf(v);
   }
 }
 
@@ -106,7 +106,7 @@ __global__ void unprep_conv_kernel(const float* __restrict__ g, int Co, int Ci, 
 // batched bf16 transpose through LDS: in [R][ld_in] (C cols) -> out [C][ld_out] (R cols, zero padded)
 __global__ __launch_bounds__(256) void transpose_kernel(const bfraw* __restrict__ in, long long in_bs, int ld_in,
                                                         bfraw* __restrict__ out, long long out_bs, int ld_out, int R, int C,
-                                                        int inner, long long in_s1, long long out_s1) {
+                                                        int inner, long long in_s1, long long out_s1, int r_pad) {
   __shared__ bfraw tile[32][33];
   const int z = blockIdx.z;
   const bfraw* ip = in + (z / inner) * in_bs + (z % inner) * in_s1;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bfraw* __restrict_
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
     const int c = c0 + k, r = r0 + tx;
-    if (c < C && r < ld_out) op[(long long)c * ld_out + r] = tile[tx][k];
+    if (c < C && r < r_pad) op[(long long)c * ld_out + r] = tile[tx][k];
   }
 }
 
@@ -203,11 +203,11 @@ extern "C" int pp_copy_2d_f32(const float* in, int ld_in, float* out, int ld_out
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
-extern "C" int pp_cast_pad_2d(const float* in, int rows, int cols, int ld_in, void* out, int rows_out, int ld_out,
-                              int transpose, pp_stream_t s) {
-  PP_CHECK_ARG(rows > 0 && cols > 0 && rows_out > 0 && ld_out > 0, "pp_cast_pad_2d: sizes");
-  hipLaunchKernelGGL(cast_pad_2d_kernel, dim3(sgrid((long long)rows_out * ld_out)), dim3(256), 0, S_, in, rows, cols, ld_in,
-                     (bfraw*)out, rows_out, ld_out, transpose);
+extern "C" int pp_cast_pad_2d(const float* in, int rows, int cols, int ld_in, void* out, int rows_out, int cols_out,
+                              int ld_out, int transpose, pp_stream_t s) {
+  PP_CHECK_ARG(rows > 0 && cols > 0 && rows_out >= rows && cols_out >= cols && ld_out >= cols_out, "pp_cast_pad_2d: sizes");
+  hipLaunchKernelGGL(cast_pad_2d_kernel, dim3(sgrid((long long)rows_out * cols_out)), dim3(256), 0, S_, in, rows, cols, ld_in,
+                     (bfraw*)out, rows_out, cols_out, ld_out, transpose);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -227,12 +227,13 @@ extern "C" int pp_unprep_conv_grad(const float* g, int Co, int Ci, int taps, int
   return PP_OK;
 }
 extern "C" int pp_transpose_bf16(const void* in, long long in_bs, int ld_in, void* out, long long out_bs, int ld_out, int nb,
-                                 int R, int C, int inner, long long in_s1, long long out_s1, pp_stream_t s) {
-  PP_CHECK_ARG(nb > 0 && R > 0 && C > 0 && ld_out >= R && ld_in >= C, "pp_transpose_bf16: sizes");
+                                 int R, int C, int inner, long long in_s1, long long out_s1, int r_pad, pp_stream_t s) {
+  if (r_pad <= 0) r_pad = ld_out;
+  PP_CHECK_ARG(nb > 0 && R > 0 && C > 0 && r_pad >= R && ld_out >= r_pad && ld_in >= C, "pp_transpose_bf16: sizes");
   if (inner <= 0) inner = 1;
-  dim3 grid((C + 31) / 32, (ld_out + 31) / 32, nb);
+  dim3 grid((C + 31) / 32, (r_pad + 31) / 32, nb);
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, S_, (const bfraw*)in, in_bs, ld_in, (bfraw*)out, out_bs, ld_out, R, C,
-                     inner, in_s1, out_s1);
+                     inner, in_s1, out_s1, r_pad);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -280,8 +280,8 @@ extern "C" size_t pp_attnpool_ws_floats(int B, int T, int F, int Hd, int E) {
 }
 
 extern "C" int pp_attnpool_fwd(const float* x, int B, int T, int F, int Hd, int E, const float* W1, const float* b1,
-                               const float* W2, const float* b2, const float* Wp, const float* bp, float* hid, float* alpha,
-                               float* pooled, float* pre, float* out, pp_stream_t s) {
+                               const float* W2, const float* b2, const float* Wp, const float* bp, int normalize, float* hid,
+                               float* alpha, float* pooled, float* pre, float* out, pp_stream_t s) {
   PP_CHECK_ARG(B > 0 && T > 0 && F > 0 && Hd > 0 && E > 0 && (Wp || E == F), "pp_attnpool_fwd: sizes");
   const int BT = B * T;
   RC(sgemm(S_, x, F, 1, W1, 1, F, hid, Hd, 1, BT, Hd, F, b1, 1));
@@ -289,14 +289,15 @@ extern "C" int pp_attnpool_fwd(const float* x, int B, int T, int F, int Hd, int 
   hipLaunchKernelGGL(timepool_fwd_kernel, dim3(B), dim3(F < 256 ? ((F + 63) / 64) * 64 : 256), 0, S_, alpha, x, pooled, T, F);
   if (Wp) RC(sgemm(S_, pooled, F, 1, Wp, 1, F, pre, E, 1, B, E, F, bp, 0));
   else hipLaunchKernelGGL(copy_f32_kernel, dim3((B * E + 255) / 256), dim3(256), 0, S_, pooled, pre, (long long)B * E);
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(256), 0, S_, pre, out, (float*)nullptr, E, 1e-12f);
+  if (normalize) hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(256), 0, S_, pre, out, (float*)nullptr, E, 1e-12f);
+  else hipLaunchKernelGGL(copy_f32_kernel, dim3((B * E + 255) / 256), dim3(256), 0, S_, pre, out, (long long)B * E);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
 
 extern "C" int pp_attnpool_bwd(const float* dout, const float* x, int B, int T, int F, int Hd, int E, const float* W1,
-                               const float* W2, const float* Wp, const float* hid, const float* alpha, const float* pooled,
-                               const float* pre, const float* out, float* dx, float* dW1, float* db1, float* dW2, float* db2,
+                               const float* W2, const float* Wp, int normalize, const float* hid, const float* alpha,
+                               const float* pooled, const float* pre, const float* out, float* dx, float* dW1, float* db1, float* dW2, float* db2,
                                float* dWp, float* dbp, float* ws, pp_stream_t s) {
   PP_CHECK_ARG(B > 0 && T > 0 && F > 0 && Hd > 0 && E > 0 && ws && (Wp || E == F), "pp_attnpool_bwd: sizes");
   const int BT = B * T;
@@ -304,7 +305,8 @@ extern "C" int pp_attnpool_bwd(const float* dout, const float* x, int B, int T, 
   float* dpooled = dpre + (size_t)B * E;
   float* de = dpooled + (size_t)B * F;
   float* da = de + (size_t)BT * F;
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, S_, dout, pre, out, dpre, E, 1e-12f);
+  if (normalize) hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, S_, dout, pre, out, dpre, E, 1e-12f);
+  else hipLaunchKernelGGL(copy_f32_kernel, dim3((B * E + 255) / 256), dim3(256), 0, S_, dout, dpre, (long long)B * E);
   if (Wp) {
     RC(sgemm(S_, dpre, 1, E, pooled, F, 1, dWp, F, 1, E, F, B));            // dWp[e][f] = sum_b dpre[b][e] pooled[b][f]
     RC(colsum_f32(S_, dpre, B, E, E, dbp));
@@ -350,6 +352,62 @@ extern "C" int pp_triplet_loss_bwd(const float* V, const float* A, int N, int D,
   RC(sgemm(S_, w.G, 1, N, w.Vn, D, 1, w.dAn, D, 1, N, D, N));   // dAn = G^T Vn
   hipLaunchKernelGGL(cosnorm_bwd_kernel, dim3(N), dim3(256), 0, S_, w.dVn, w.Vn, w.vnorm, dloss, dV, D);
   hipLaunchKernelGGL(cosnorm_bwd_kernel, dim3(N), dim3(256), 0, S_, w.dAn, w.An, w.anorm, dloss, dA, D);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---- API-surface helpers: pig/loss.py:51-55 cosine_matrix, pig/loss.py:41-48 contrastive (forward),
+//      pig/metrics.py:45-52 triplet_accuracy --------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void triplet_acc_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                          const float* __restrict__ n, int D, int discrete, float* out) {
+  __shared__ float red[4];
+  const long long r = blockIdx.x;
+  float aa = 0.f, pp = 0.f, nn = 0.f, ap = 0.f, an = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float x = a[r * D + d], y = p[r * D + d], z = n[r * D + d];
+    aa += x * x; pp += y * y; nn += z * z; ap += x * y; an += x * z;
+  }
+  aa = block_sum<4>(aa, red); pp = block_sum<4>(pp, red); nn = block_sum<4>(nn, red);
+  ap = block_sum<4>(ap, red); an = block_sum<4>(an, red);
+  if (threadIdx.x == 0) {
+    // torch 1.9.1 F.cosine_similarity: w12 / sqrt(clamp(w1*w2, eps^2)), eps = 1e-8
+    const float eps2 = 1e-16f;
+    const float sp = ap / sqrtf(fmaxf(aa * pp, eps2)), sn = an / sqrtf(fmaxf(aa * nn, eps2));
+    const float diff = sp - sn;
+    out[r] = discrete ? ((diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) + 1.f) * 0.5f : diff;
+  }
+}
+}  // namespace
+
+extern "C" int pp_triplet_accuracy(const float* a, const float* p, const float* n, int M, int D, int discrete, float* out,
+                                   pp_stream_t s) {
+  PP_CHECK_ARG(M > 0 && D > 0 && a && p && n && out, "pp_triplet_accuracy: bad arguments");
+  hipLaunchKernelGGL(triplet_acc_kernel, dim3(M), dim3(256), 0, S_, a, p, n, D, discrete, out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_cosine_matrix(const float* U, const float* Vv, int Nu, int Nv, int D, float* out, float* ws,
+                                pp_stream_t s) {
+  PP_CHECK_ARG(Nu > 0 && Nv > 0 && D > 0 && U && Vv && out && ws, "pp_cosine_matrix: bad arguments");
+  float* Un = ws;
+  float* Vn = ws + (size_t)Nu * D;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(Nu), dim3(256), 0, S_, U, Un, (float*)nullptr, D, 0.f);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(Nv), dim3(256), 0, S_, Vv, Vn, (float*)nullptr, D, 0.f);
+  RC(sgemm(S_, Un, D, 1, Vn, 1, D, out, Nv, 1, Nu, Nv, D));
+  return PP_OK;
+}
+
+extern "C" int pp_contrastive_fwd(const float* S, int N, float margin, float* loss, float* ws, pp_stream_t s) {
+  PP_CHECK_ARG(N > 0 && S && loss && ws, "pp_contrastive_fwd: bad arguments");
+  float* G = ws;                      // N*N copy (hinge_kernel overwrites its input)
+  float* diag = G + (size_t)N * N;
+  float* rowc = diag + N;
+  float* colc = rowc + N;
+  hipLaunchKernelGGL(copy_f32_kernel, dim3((N * N + 255) / 256), dim3(256), 0, S_, S, G, (long long)N * N);
+  hipLaunchKernelGGL(diag_kernel, dim3((N + 255) / 256), dim3(256), 0, S_, G, diag, rowc, colc, loss, N);
+  hipLaunchKernelGGL(hinge_kernel, dim3(N), dim3(256), 0, S_, G, diag, rowc, colc, loss, N, margin);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

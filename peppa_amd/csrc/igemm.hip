@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const pp_igemm_desc p, const
         if (m < p.M && col < ncols_store) {
           uint4 v = *(const uint4*)(stg + row * STG_STRIDE + ch * 16);
           if (p.residual && !pre_pass) {
-            const uint4 rv = *(const uint4*)((const bfraw*)p.residual + (long long)m * p.ldr + col);
+            const uint4 rv = *(const uint4*)((const bfraw*)p.residual + c_off + (long long)m * p.ldr + col);
             float a[8], b[8];
             unpack8(v, a);
             unpack8(rv, b);
@@ -373,7 +373,7 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   if (!d.c_fp32) {
     PP_CHECK_ARG(d.ldc % 8 == 0 && d.ldc >= ((d.N + 7) & ~7), "pp_igemm: ldc=%d too small / unaligned for N=%d", d.ldc, d.N);
     PP_CHECK_ARG(((uintptr_t)d.C & 15) == 0, "pp_igemm: C must be 16-byte aligned");
-    if (d.residual) PP_CHECK_ARG(d.ldr % 8 == 0 && d.nbatch == 1, "pp_igemm: residual needs ldr%%8==0 and nbatch==1");
+    if (d.residual) PP_CHECK_ARG(d.ldr % 8 == 0, "pp_igemm: residual needs ldr%%8==0 (batched: same offsets as C)");
   } else {
     PP_CHECK_ARG(!d.residual && !d.Cpre && !d.colstats, "pp_igemm: fp32 output supports bias/act only");
   }

@@ -88,8 +88,9 @@ def unprep_conv_grad(g, dw, Co, Ci, taps, cg):
     call("pp_unprep_conv_grad", _p(g, f32), Co, Ci, taps, cg, _p(dw, f32), _s())
 
 
-def cast_pad_2d(inp, out, rows, cols, ld_in, rows_out, ld_out, transpose=False):
-    call("pp_cast_pad_2d", _p(inp, f32), rows, cols, ld_in, _p(out, bf16), rows_out, ld_out, int(transpose), _s())
+def cast_pad_2d(inp, out, rows, cols, ld_in, rows_out, ld_out, transpose=False, cols_out=None):
+    call("pp_cast_pad_2d", _p(inp, f32), rows, cols, ld_in, _p(out, bf16), rows_out,
+         ld_out if cols_out is None else cols_out, ld_out, int(transpose), _s())
 
 
 def cast_f32_to_bf16(inp, out):
@@ -104,9 +105,9 @@ def copy_2d_f32(inp, ld_in, out, ld_out, rows, cols):
     call("pp_copy_2d_f32", _p(inp, f32), ld_in, _p(out, f32), ld_out, rows, cols, _s())
 
 
-def transpose_bf16(inp, in_bs, ld_in, out, out_bs, ld_out, nb, R, Ccols, inner=1, in_s1=0, out_s1=0):
+def transpose_bf16(inp, in_bs, ld_in, out, out_bs, ld_out, nb, R, Ccols, inner=1, in_s1=0, out_s1=0, r_pad=0):
     call("pp_transpose_bf16", _p(inp, bf16), in_bs, ld_in, _p(out, bf16), out_bs, ld_out, nb, R, Ccols, inner,
-         in_s1, out_s1, _s())
+         in_s1, out_s1, r_pad, _s())
 
 
 def fill_f32(t, v):
@@ -125,6 +126,11 @@ def bn_finalize(partials, nblk, ldstat, count, Cn, Cp, gamma, beta, eps, momentu
                 scale, shift):
     call("pp_bn_finalize", _p(partials, f32), nblk, ldstat, count, Cn, Cp, _p(gamma, f32), _p(beta, f32), eps,
          momentum, _p(rmean, f32), _p(rvar, f32), _p(mean, f32), _p(rstd, f32), _p(scale, f32), _p(shift, f32), _s())
+
+
+def bn_eval_affine(gamma, beta, rmean, rvar, eps, Cn, Cp, scale, shift):
+    call("pp_bn_eval_affine", _p(gamma, f32), _p(beta, f32), _p(rmean, f32), _p(rvar, f32), eps, Cn, Cp, _p(scale, f32),
+         _p(shift, f32), _s())
 
 
 def colstats_bf16(y, M, Cp, partials, nblk):
@@ -224,9 +230,10 @@ def spatial_mean_bwd(dout, dx, B, T, HW, Cn, Cp):
     call("pp_spatial_mean_bwd", _p(dout, f32), _p(dx, bf16), B, T, HW, Cn, Cp, _s())
 
 
-def attnpool_fwd(x, B, T, Fdim, Hd, E, W1, b1, W2, b2, Wp, bp, hid, alpha, pooled, pre, out):
+def attnpool_fwd(x, B, T, Fdim, Hd, E, W1, b1, W2, b2, Wp, bp, hid, alpha, pooled, pre, out, normalize=True):
     call("pp_attnpool_fwd", _p(x, f32), B, T, Fdim, Hd, E, _p(W1, f32), _p(b1, f32), _p(W2, f32), _p(b2, f32),
-         _p(Wp, f32), _p(bp, f32), _p(hid, f32), _p(alpha, f32), _p(pooled, f32), _p(pre, f32), _p(out, f32), _s())
+         _p(Wp, f32), _p(bp, f32), int(normalize), _p(hid, f32), _p(alpha, f32), _p(pooled, f32), _p(pre, f32), _p(out, f32),
+         _s())
 
 
 def attnpool_ws_floats(B, T, Fdim, Hd, E):
@@ -234,9 +241,9 @@ def attnpool_ws_floats(B, T, Fdim, Hd, E):
 
 
 def attnpool_bwd(dout, x, B, T, Fdim, Hd, E, W1, W2, Wp, hid, alpha, pooled, pre, out, dx, dW1, db1, dW2, db2, dWp,
-                 dbp, ws):
+                 dbp, ws, normalize=True):
     call("pp_attnpool_bwd", _p(dout, f32), _p(x, f32), B, T, Fdim, Hd, E, _p(W1, f32), _p(W2, f32), _p(Wp, f32),
-         _p(hid, f32), _p(alpha, f32), _p(pooled, f32), _p(pre, f32), _p(out, f32), _p(dx, f32), _p(dW1, f32),
+         int(normalize), _p(hid, f32), _p(alpha, f32), _p(pooled, f32), _p(pre, f32), _p(out, f32), _p(dx, f32), _p(dW1, f32),
          _p(db1, f32), _p(dW2, f32), _p(db2, f32), _p(dWp, f32), _p(dbp, f32), _p(ws, f32), _s())
 
 
@@ -254,6 +261,21 @@ def triplet_loss_fwd(V, A, margin, loss, ws):
 def triplet_loss_bwd(V, A, dloss, ws, dV, dA):
     N, D = V.shape
     call("pp_triplet_loss_bwd", _p(V, f32), _p(A, f32), N, D, _p(dloss, f32), _p(ws), _p(dV, f32), _p(dA, f32), _s())
+
+
+def cosine_matrix(U, V, out):
+    ws = torch.empty((U.shape[0] + V.shape[0]) * U.shape[1], dtype=f32, device=U.device)
+    call("pp_cosine_matrix", _p(U, f32), _p(V, f32), U.shape[0], V.shape[0], U.shape[1], _p(out, f32), _p(ws, f32), _s())
+
+
+def contrastive_fwd(S, margin, loss):
+    N = S.shape[0]
+    ws = torch.empty(N * N + 3 * N, dtype=f32, device=S.device)
+    call("pp_contrastive_fwd", _p(S, f32), N, margin, _p(loss, f32), _p(ws, f32), _s())
+
+
+def triplet_accuracy(a, p, n, discrete, out):
+    call("pp_triplet_accuracy", _p(a, f32), _p(p, f32), _p(n, f32), a.shape[0], a.shape[1], int(discrete), _p(out, f32), _s())
 
 
 # ---- optimizer -------------------------------------------------------------------------------------

@@ -138,9 +138,12 @@ def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momen
     sv = BNSaved()
     sv.count, sv.C, sv.Cp = count, C, Cp
     sv.mean, sv.rstd, sv.scale, sv.shift = (empty((Cp,), f32, y) for _ in range(4))
-    H.bn_finalize(partials, nblk, Cp, count, C, Cp, bn.weight, bn.bias, eps, momentum,
-                  bn.running_mean if update_running else None, bn.running_var if update_running else None,
-                  sv.mean, sv.rstd, sv.scale, sv.shift)
+    if partials is None:  # eval mode: running statistics (no backward through this path)
+        H.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, eps, C, Cp, sv.scale, sv.shift)
+    else:
+        H.bn_finalize(partials, nblk, Cp, count, C, Cp, bn.weight, bn.bias, eps, momentum,
+                      bn.running_mean if update_running else None, bn.running_var if update_running else None,
+                      sv.mean, sv.rstd, sv.scale, sv.shift)
     z = empty(y.shape, bf16, y)
     H.bn_apply(y, sv.scale, sv.shift, residual, relu, z, y.shape[0], Cp)
     return z, sv

@@ -1,0 +1,314 @@
+"""`pig.models` on MI355X: same classes, constructor arguments, attribute names and errors as
+the reference (pig/models.py:30-342); every forward runs hand-written HIP kernels through
+libpeppa_hip.so.  CPU tensors are rejected (PeppaHipError) -- there is no fallback path.
+"""
+import logging
+import torch
+from torch import nn
+
+from . import hip as H
+from . import layers as L
+from . import audio as A
+from . import video as V
+from .hip import f32, bf16
+from .loss import TripletLoss
+from . import metrics as _metrics
+from . import optimization as opt
+from .data import ClipBatch
+from .triplet import TripletBatch as EmbeddingTripletBatch, score_triplets
+from .transforms import SwapCT  # noqa: F401  (API surface)
+
+try:  # the reference subclasses LightningModule; Lightning is optional here
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - Lightning absent in this image
+    pl = None
+    _Base = nn.Module
+
+
+class TargetedTripletBatch:
+    """Shape contract of pig/targeted_triplets.py:28-33 (anchor audio, positive/negative video)."""
+
+    def __init__(self, anchor, positive, negative):
+        self.anchor, self.positive, self.negative = anchor, positive, negative
+
+
+class AttnPoolFn(torch.autograd.Function):
+    """softmax-over-time attention pooling (+ optional Linear projection, + optional F.normalize)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, Wp, bp, normalize):
+        if not x.is_cuda:
+            raise H.PeppaHipError("peppa_amd pooling needs a CUDA/HIP tensor (no CPU fallback)")
+        x = x.contiguous().float()
+        B, T, Fd = x.shape
+        Hd = W1.shape[0]
+        E = Wp.shape[0] if Wp is not None else Fd
+        e = lambda *s: torch.empty(*s, dtype=f32, device=x.device)
+        hid, alpha, pooled, pre, out = e(B, T, Hd), e(B, T, Fd), e(B, Fd), e(B, E), e(B, E)
+        H.attnpool_fwd(x, B, T, Fd, Hd, E, W1, b1, W2, b2, Wp, bp, hid, alpha, pooled, pre, out, normalize=normalize)
+        ctx.save_for_backward(x, W1, W2, Wp, hid, alpha, pooled, pre, out)
+        ctx.dims, ctx.normalize = (B, T, Fd, Hd, E), normalize
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W1, W2, Wp, hid, alpha, pooled, pre, out = ctx.saved_tensors
+        B, T, Fd, Hd, E = ctx.dims
+        e = lambda *s: torch.empty(*s, dtype=f32, device=x.device)
+        dx, dW1, db1, dW2, db2 = e(B, T, Fd), e(Hd, Fd), e(Hd), e(Fd, Hd), e(Fd)
+        dWp, dbp = (e(E, Fd), e(E)) if Wp is not None else (None, None)
+        ws = e(H.attnpool_ws_floats(B, T, Fd, Hd, E))
+        H.attnpool_bwd(dout.contiguous().float(), x, B, T, Fd, Hd, E, W1, W2, Wp, hid, alpha, pooled, pre, out, dx,
+                       dW1, db1, dW2, db2, dWp, dbp, ws, normalize=ctx.normalize)
+        return dx, dW1, db1, dW2, db2, dWp, dbp, None
+
+
+class Attention(nn.Module):
+    def __init__(self, in_size, hidden_size):
+        super().__init__()
+        self.hidden = nn.Linear(in_size, hidden_size)
+        self.out = nn.Linear(hidden_size, in_size)
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, input):
+        return AttnPoolFn.apply(input, self.hidden.weight, self.hidden.bias, self.out.weight, self.out.bias, None,
+                                None, False)
+
+    def pooled_projected(self, input, project):
+        """Fused pooling + Linear + F.normalize(p=2, dim=1) (the tail of both encoders)."""
+        return AttnPoolFn.apply(input, self.hidden.weight, self.hidden.bias, self.out.weight, self.out.bias,
+                                project.weight, project.bias, True)
+
+
+def _hip_todo(what):
+    raise NotImplementedError(f"{what} is not on the HIP path yet (no committed hparams_*.yaml selects it); "
+                              "see DESIGN.md 'Out of scope / next'")
+
+
+class AveragePool(nn.Module):
+    def __init__(self, size=512):
+        super().__init__()
+        self.pool = torch.nn.AdaptiveAvgPool2d((size, 1))
+
+    def forward(self, x):
+        _hip_todo("audio pooling 'average'")
+
+
+class LastStep(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, x):
+        _hip_todo("audio pooling 'last'")
+
+
+class Wav2VecEncoder(nn.Module):
+    def __init__(self, path, pretrained=True, freeze_feature_extractor=False, freeze_encoder_layers=None,
+                 pooling='average', project=True, full=False):
+        super().__init__()
+        if pretrained:
+            self.audio = _load_fairseq_checkpoint(path)
+        else:
+            self.audio = A.wav2vec2_base(num_out=28)
+        if freeze_feature_extractor:
+            for param in self.audio.feature_extractor.parameters():
+                param.requires_grad = False
+        if freeze_encoder_layers is not None:
+            for index in range(0, freeze_encoder_layers):
+                for param in self.audio.encoder.transformer.layers[index].parameters():
+                    param.requires_grad = False
+        self.full = full
+        self.n_features = 28 if self.full else 512
+        if pooling == 'average':
+            self.audiopool = AveragePool(size=self.n_features)
+        elif pooling == 'attention':
+            self.audiopool = Attention(self.n_features, 128)
+        elif pooling == 'last':
+            self.audiopool = LastStep()
+        else:
+            raise ValueError(f"Invalid pooling: {pooling}")
+        self.project = nn.Linear(self.n_features, 512) if project else nn.Identity()
+
+    def forward(self, x):
+        wave = x.squeeze(dim=1)
+        if self.full:
+            features, _ = self.audio(wave)
+        else:
+            features, _ = self.audio.extract_features(wave)
+        if isinstance(self.audiopool, Attention) and isinstance(self.project, nn.Linear):
+            return self.audiopool.pooled_projected(features, self.project)
+        _hip_todo("audio head other than attention pooling + projection")
+
+
+def _load_fairseq_checkpoint(path):
+    raise RuntimeError(f"audio.pretrained=true needs the fairseq checkpoint {path!r} and fairseq itself "
+                       "(pig/models.py:70-72); neither is available offline. Use pretrained: false or load a "
+                       "state_dict with torchaudio parameter names.")
+
+
+class VideoTrunkFn(torch.autograd.Function):
+    """(B,3,T,H,W) fp32 in [0,1] -> spatial means of the trunk output, (B,T',512) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, enc, want_grad, *params):
+        if not x.is_cuda:
+            raise H.PeppaHipError("peppa_amd.video needs a CUDA/HIP tensor (no CPU fallback)")
+        x = x.contiguous().float()
+        net = enc.video
+        save = want_grad and any(ctx.needs_input_grad)  # grad mode is always off inside Function.forward
+        if save and not net.training:
+            raise RuntimeError("backward through eval-mode BatchNorm is not supported on the HIP path")
+        with torch.no_grad():
+            z, thw, tape = V.trunk_forward(net, x, enc.norm_kind, net.training, save)
+            B = x.shape[0]
+            Tn, HW = thw[0], thw[1] * thw[2]
+            out = torch.empty(B, Tn, 512, dtype=f32, device=x.device)
+            H.spatial_mean_fwd(z, out, B, Tn, HW, 512, z.shape[1])
+        ctx.tape, ctx.params, ctx.dims = tape, params, (B, Tn, HW, z.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Tn, HW, Cp = ctx.dims
+        grads = {}
+        with torch.no_grad():
+            dz = torch.empty(B * Tn * HW, Cp, dtype=bf16, device=dout.device)
+            H.spatial_mean_bwd(dout.contiguous().float(), dz, B, Tn, HW, 512, Cp)
+            V.trunk_backward(ctx.tape, dz, grads)
+        ctx.tape = None
+        return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+class R3DEncoder(nn.Module):
+    def __init__(self, pretrained=True, project=True, version='r3d_18', pooling='average'):
+        super().__init__()
+        self.pretrained = pretrained
+        if version not in ('r3d_18', 'mc3_18', 'r2plus1d_18'):
+            raise ValueError(f"Invalid version {version}")
+        if pretrained:
+            logging.warning("video.pretrained=true: Kinetics weights cannot be downloaded offline; using random "
+                            "init with the kinetics normalisation constants (load a state_dict to override)")
+        self.video = V.VideoResNet(version)
+        self.project = nn.Linear(512, 512) if project else nn.Identity()
+        if pooling == 'attention':
+            self.videopool = VideoAttention(512, 128)
+        elif pooling == 'average':
+            self.videopool = VideoAveragePool()
+        else:
+            raise ValueError(f"Invalid pooling {pooling}")
+        self.norm_kind = "kinetics" if self.pretrained else "peppa"
+        self.transform = build_transform(self.norm_kind)
+
+    def forward(self, x):
+        feats = VideoTrunkFn.apply(x, self, torch.is_grad_enabled(), *self.video.trunk_parameters())
+        if isinstance(self.videopool, VideoAttention) and isinstance(self.project, nn.Linear):
+            return self.videopool.attn.pooled_projected(feats, self.project)
+        _hip_todo("video head other than attention pooling + projection")
+
+
+class ImageEncoder(nn.Module):
+    def __init__(self, pretrained=True, project=True, pooling='average'):
+        super().__init__()
+        _hip_todo("the static ImageEncoder (hparams_static.yaml, resnet18 per frame)")
+
+
+class VideoAveragePool(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.pool = torch.nn.AdaptiveAvgPool3d(output_size=(1, 1, 1))
+
+    def forward(self, x):
+        _hip_todo("video pooling 'average'")
+
+
+class VideoAttention(nn.Module):
+    def __init__(self, in_size=512, hidden_size=128):
+        super().__init__()
+        self.spatial_avg = torch.nn.AdaptiveAvgPool2d(output_size=(1, 1))
+        self.attn = Attention(in_size, hidden_size)
+
+    def forward(self, x):
+        """x: spatial means (B,T',512) as produced by VideoTrunkFn."""
+        return self.attn(x)
+
+
+class PeppaPig(_Base):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        if pl is not None:
+            self.save_hyperparameters(config)
+        self.loss = TripletLoss(margin=self.config['margin'])
+        static = self.config['video'].get('static', False)
+        video_config = {key: value for key, value in self.config['video'].items() if key != 'static'}
+        if static:
+            self.video_encoder = ImageEncoder(**video_config)
+        else:
+            self.video_encoder = R3DEncoder(**video_config)
+        self.audio_encoder = Wav2VecEncoder(**config['audio'])
+        self._logged = {}
+
+    if pl is None:
+        def log(self, name, value, **kwargs):
+            self._logged[name] = value
+
+    def forward(self, batch):
+        if isinstance(batch, TargetedTripletBatch):
+            a = self.encode_audio(batch.anchor)
+            p = self.encode_video(batch.positive)
+            n = self.encode_video(batch.negative)
+            return EmbeddingTripletBatch(anchor=a, positive=p, negative=n)
+        V_ = self.encode_video(batch.video)
+        A_ = self.encode_audio(batch.audio)
+        return ClipBatch(video=V_, audio=A_, video_duration=batch.video_duration,
+                         audio_duration=batch.audio_duration)
+
+    def encode_video(self, x):
+        return self.video_encoder(x)
+
+    def encode_audio(self, x):
+        return self.audio_encoder(x)
+
+    def training_step(self, batch, batch_idx):
+        V_ = self.encode_video(batch.video)
+        A_ = self.encode_audio(batch.audio)
+        loss = self.loss(V_, A_)
+        # the reference logs loss.item() (a host sync per step, pig/models.py:264); log the tensor instead
+        self.log("train_loss", loss.detach(), prog_bar=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx, dataloader_idx=None):
+        V_ = self.encode_video(batch.video)
+        A_ = self.encode_audio(batch.audio)
+        if dataloader_idx == 0:
+            self.log("val_loss", self.loss(V_, A_).detach(), prog_bar=True)
+            return (V_, A_)
+        elif dataloader_idx == 1:
+            self.log("valnarr_loss", self.loss(V_, A_).detach(), prog_bar=False)
+            return (V_, A_)
+        elif dataloader_idx in [2, 3]:
+            return (V_, A_, batch.audio_duration)
+        raise ValueError(f"Invalid dataloader index {dataloader_idx}")
+
+    def validation_epoch_end(self, outputs):
+        out_main, out_narr, out_dia3, out_narr3 = outputs
+        for name, out in (("val_rec_fixed", out_main), ("valnarr_rec_fixed", out_narr)):
+            Vs, As = zip(*out)
+            rec = _metrics.resampled_recall(torch.cat(Vs, dim=0), torch.cat(As, dim=0), size=100, n_samples=500, n=10)
+            self.log(name, rec.mean(), prog_bar=True)
+        for name, out in (("val_triplet", out_dia3), ("valnarr_triplet", out_narr3)):
+            Vs, As, Ds = zip(*out)
+            tri = score_triplets(torch.cat(Vs, dim=0), torch.cat(As, dim=0), torch.cat(Ds, dim=0), n_samples=500)
+            self.log(name, tri.mean(), prog_bar=True)
+
+    def configure_optimizers(self):
+        return opt.BertAdam(self.parameters(), **self.config['optimizer'])
+
+
+def build_transform(normalization):
+    """Returns the (mean, std) the HIP input kernel applies; the reference's permute -> Normalize ->
+    permute (pig/models.py:327-342) is fused into the NCDHW->NDHWC load of the stem."""
+    if normalization not in V.VIDEO_STATS:
+        raise ValueError(f"Unsupported normalization type {normalization}")
+    return V.VIDEO_STATS[normalization]

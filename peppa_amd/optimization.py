@@ -1,0 +1,129 @@
+"""`pig.optimization` (pig/optimization.py:26-179): BertAdam and its schedules.
+
+Same constructor, defaults, state names (`step`, `next_m`, `next_v`) and update rule as the
+reference: per-tensor gradient clipping, no bias correction, epsilon outside the square root,
+decoupled weight decay on every tensor, schedule multiplier from the per-tensor step count
+(0 at step 0).  The update itself is one fused multi-tensor HIP launch pair instead of ~10
+elementwise kernels per parameter tensor."""
+import math
+import logging
+import torch
+from torch.optim import Optimizer
+from torch.optim.optimizer import required
+
+from . import hip as H
+from .hip import f32
+
+logger = logging.getLogger(__name__)
+
+
+def warmup_cosine(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return 0.5 * (1.0 + math.cos(math.pi * x))
+
+
+def warmup_constant(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return 1.0
+
+
+def warmup_linear(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return max((x - 1.) / (warmup - 1.), 0)
+
+
+SCHEDULES = {
+    'warmup_cosine': warmup_cosine,
+    'warmup_constant': warmup_constant,
+    'warmup_linear': warmup_linear,
+}
+
+_CHUNK = 65536
+
+
+class BertAdam(Optimizer):
+    def __init__(self, params, lr=required, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999,
+                 e=1e-6, weight_decay=0.01, max_grad_norm=1.0):
+        if lr is not required and lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if schedule not in SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
+        if not 0.0 <= warmup < 1.0 and not warmup == -1:
+            raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
+        if not 0.0 <= b1 < 1.0:
+            raise ValueError("Invalid b1 parameter: {} - should be in [0.0, 1.0[".format(b1))
+        if not 0.0 <= b2 < 1.0:
+            raise ValueError("Invalid b2 parameter: {} - should be in [0.0, 1.0[".format(b2))
+        if not e >= 0.0:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(e))
+        defaults = dict(lr=lr, schedule=schedule, warmup=warmup, t_total=t_total, b1=b1, b2=b2, e=e,
+                        weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        super(BertAdam, self).__init__(params, defaults)
+        self._chunk_cache = {}
+
+    def _lr(self, group, step):
+        if group['t_total'] != -1:
+            return group['lr'] * SCHEDULES[group['schedule']](step / group['t_total'], group['warmup'])
+        return group['lr']
+
+    def get_lr(self):
+        lr = []
+        for group in self.param_groups:
+            for p in group['params']:
+                state = self.state[p]
+                if len(state) == 0:
+                    return [0]
+                lr.append(self._lr(group, state['step']))
+        return lr
+
+    def _chunks(self, numels, device):
+        key = (tuple(numels), str(device))
+        if key not in self._chunk_cache:
+            ct, co = [], []
+            for i, n in enumerate(numels):
+                for off in range(0, n, _CHUNK):
+                    ct.append(i)
+                    co.append(off)
+            self._chunk_cache[key] = (torch.tensor(ct, dtype=torch.int32, device=device),
+                                      torch.tensor(co, dtype=torch.int64, device=device), len(ct),
+                                      torch.empty(len(numels), dtype=f32, device=device))
+        return self._chunk_cache[key]
+
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            loss = closure()
+        warned = False
+        for group in self.param_groups:
+            buckets = {}  # same step count and device -> one fused launch
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError('Adam does not support sparse gradients, please consider SparseAdam instead')
+                if not p.is_cuda:
+                    raise H.PeppaHipError("BertAdam on the HIP path needs CUDA/HIP parameters (no CPU fallback)")
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = 0
+                    state['next_m'] = torch.zeros_like(p.data)
+                    state['next_v'] = torch.zeros_like(p.data)
+                buckets.setdefault((state['step'], p.device), []).append(p)
+            for (step, device), ps in buckets.items():
+                if (group['t_total'] != -1 and group['schedule'] == "warmup_linear" and
+                        step / group['t_total'] > 1. and not warned):
+                    logger.warning("Training beyond specified 't_total' steps with schedule '{}'.".format(group['schedule']))
+                    warned = True
+                gs = [p.grad.data if p.grad.is_contiguous() else p.grad.data.contiguous() for p in ps]
+                ms = [self.state[p]['next_m'] for p in ps]
+                vs = [self.state[p]['next_v'] for p in ps]
+                tl, keep = H.make_tensor_list([p.data for p in ps], gs, ms, vs, device)
+                ct, co, n_chunks, norms = self._chunks([p.numel() for p in ps], device)
+                H.bertadam_step(tl, ct, co, n_chunks, _CHUNK, norms, float(self._lr(group, step)), group['b1'],
+                                group['b2'], group['e'], group['weight_decay'], group['max_grad_norm'])
+                for p in ps:
+                    self.state[p]['step'] += 1
+        return loss

@@ -1,0 +1,232 @@
+"""Video trunks (r2plus1d_18 / r3d_18 / mc3_18) on the HIP path.
+
+Module tree and parameter names equal torchvision 0.10.1 `models.video.resnet.VideoResNet`
+(`stem`, `layer1..4`, `avgpool`, `fc`), which is what `pig/models.py:122-127,141-150` builds and
+what its checkpoints store.  The torch.nn modules below are parameter containers only: the
+forward/backward of the trunk is a hand-scheduled chain of HIP kernels (implicit-GEMM convs with a
+BatchNorm-statistics epilogue, streaming BN apply / backward passes) driven by `TrunkFn`.
+"""
+import torch
+from torch import nn
+
+from . import hip as H
+from . import layers as L
+from .hip import bf16, f32
+
+VIDEO_STATS = {  # data/out/stats.pt, data/out/kinetics-stats.pt, pig/models.py:335-336
+    "peppa": ((0.62745821, 0.66273642, 0.66865104), (0.24167268, 0.20884572, 0.27490067)),
+    "kinetics": ((0.43216, 0.394666, 0.37645), (0.22803, 0.22145, 0.216989)),
+    "imagenet": ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)),
+}
+
+
+def _conv(ci, co, k, s, p):
+    return nn.Conv3d(ci, co, k, stride=s, padding=p, bias=False)
+
+
+def _conv2plus1d(ci, co, mid, stride=1):
+    return nn.Sequential(_conv(ci, mid, (1, 3, 3), (1, stride, stride), (0, 1, 1)), nn.BatchNorm3d(mid),
+                         nn.ReLU(inplace=True), _conv(mid, co, (3, 1, 1), (stride, 1, 1), (1, 0, 0)))
+
+
+def _conv3dsimple(ci, co, mid=None, stride=1):
+    return _conv(ci, co, (3, 3, 3), stride, 1)
+
+
+def _conv3dnotemporal(ci, co, mid=None, stride=1):
+    return _conv(ci, co, (1, 3, 3), (1, stride, stride), (0, 1, 1))
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, ci, planes, builder, stride=1, downsample=None):
+        super().__init__()
+        mid = (ci * planes * 27) // (ci * 9 + 3 * planes)
+        self.conv1 = nn.Sequential(builder(ci, planes, mid, stride), nn.BatchNorm3d(planes), nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(builder(planes, planes, mid), nn.BatchNorm3d(planes))
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+
+class VideoResNet(nn.Module):
+    def __init__(self, version="r2plus1d_18"):
+        super().__init__()
+        if version == "r2plus1d_18":
+            builders = [_conv2plus1d] * 4
+            self.stem = nn.Sequential(_conv(3, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3)), nn.BatchNorm3d(45),
+                                      nn.ReLU(inplace=True), _conv(45, 64, (3, 1, 1), 1, (1, 0, 0)),
+                                      nn.BatchNorm3d(64), nn.ReLU(inplace=True))
+        elif version in ("r3d_18", "mc3_18"):
+            builders = [_conv3dsimple] * 4 if version == "r3d_18" else [_conv3dsimple] + [_conv3dnotemporal] * 3
+            self.stem = nn.Sequential(_conv(3, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3)), nn.BatchNorm3d(64),
+                                      nn.ReLU(inplace=True))
+        else:
+            raise ValueError(f"Invalid version {version}")
+        self.version = version
+        self._inplanes = 64
+        self.layer1 = self._make_layer(builders[0], 64, 1)
+        self.layer2 = self._make_layer(builders[1], 128, 2)
+        self.layer3 = self._make_layer(builders[2], 256, 2)
+        self.layer4 = self._make_layer(builders[3], 512, 2)
+        self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))  # unused by the reference
+        self.fc = nn.Linear(512, 400)                   # unused by the reference
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm3d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, builder, planes, stride):
+        ds = None
+        if stride != 1 or self._inplanes != planes:
+            ds_stride = (1, stride, stride) if builder is _conv3dnotemporal else (stride, stride, stride)
+            ds = nn.Sequential(_conv(self._inplanes, planes, 1, ds_stride, 0), nn.BatchNorm3d(planes))
+        blocks = [BasicBlock(self._inplanes, planes, builder, stride, ds), BasicBlock(planes, planes, builder)]
+        self._inplanes = planes
+        return nn.Sequential(*blocks)
+
+    # ---- execution plan ---------------------------------------------------------------------------
+    @staticmethod
+    def _cbr(seq):
+        """Flatten a module into [conv, bn, relu?] units in execution order."""
+        mods = [m for m in seq.modules() if isinstance(m, (nn.Conv3d, nn.BatchNorm3d, nn.ReLU))]
+        out, i = [], 0
+        while i < len(mods):
+            conv, bn = mods[i], mods[i + 1]
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            out.append([conv, bn, relu])
+            i += 3 if relu else 2
+        return out
+
+    def stem_plan(self):
+        return [("unit", *u) for u in self._cbr(self.stem)]
+
+    @classmethod
+    def block_plan(cls, blk):
+        """('block_begin', ds) , inner ('unit', conv, bn, relu)..., ('block_last', conv, bn, ds)."""
+        us = cls._cbr(blk.conv1) + cls._cbr(blk.conv2)
+        return ([("block_begin", blk.downsample)] + [("unit", *u) for u in us[:-1]] +
+                [("block_last", us[-1][0], us[-1][1], blk.downsample)])
+
+    def units(self):
+        plan = self.stem_plan()
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                plan += self.block_plan(blk)
+        return plan
+
+    def trunk_parameters(self):
+        """Parameters used by the trunk, in plan order (fc is excluded)."""
+        ps = []
+        for m in self.modules():
+            if isinstance(m, (nn.Conv3d, nn.BatchNorm3d)):
+                ps += list(m.parameters(recurse=False))
+        return ps
+
+
+def _geom(conv, B, thw, first=False):
+    ci = conv.in_channels
+    kw = dict(in_cstride=8, cg_in=8) if first else {}
+    return L.ConvGeom(B, thw, ci, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, **kw)
+
+
+class _Tape:
+    pass
+
+
+def trunk_forward(net, x, norm_kind, training, save):
+    """x fp32 [B][3][T][H][W] -> (z bf16 [B*T'*H'*W'][512], (T',H',W'), tape)."""
+    B, _, T, Hh, W = x.shape
+    mean, std = VIDEO_STATS[norm_kind]
+    cur = L.empty((B * T * Hh * W, 8), bf16, x)
+    H.video_normalize_ndhwc(x, cur, mean, std)
+    return run_plan(net.units(), cur, (T, Hh, W), B, training, save, first=True)
+
+
+def run_plan(plan, cur, thw, B, training, save, first=False):
+    """Run a (partial) unit plan on a channels-last bf16 activation [B*T*H*W][Cp]."""
+    tape = []
+    block_in = block_thw = None
+
+    def run_unit(conv, bn, relu, inp, thw_in, residual=None, first=False):
+        geom = _geom(conv, B, thw_in, first)
+        need_dgrad = save and not first
+        wf, wd = L.prep_conv_weights(conv.weight, geom, need_dgrad=need_dgrad)
+        # train mode: batch statistics from the conv epilogue; eval mode: running statistics
+        y, partials = L.conv_fwd(inp, geom, wf, stats=training)
+        z, sv = L.bn_fwd(y, partials, geom.nblk, geom.M, bn, relu=relu, residual=residual, eps=bn.eps,
+                         momentum=bn.momentum, update_running=training)
+        rec = None
+        if save:
+            rec = _Tape()
+            rec.conv, rec.bn, rec.relu, rec.geom, rec.wd = conv, bn, relu, geom, wd
+            rec.x, rec.y, rec.z, rec.sv, rec.first = inp, y, z, sv, first
+        return z, geom.out_thw, rec
+
+    for item in plan:
+        if item[0] == "unit":
+            _, conv, bn, relu = item
+            cur, thw, rec = run_unit(conv, bn, relu, cur, thw, first=first)
+            first = False
+            tape.append(("unit", rec))
+        elif item[0] == "block_begin":
+            block_in, block_thw = cur, thw
+            tape.append(("block_begin", None))
+        else:  # block_last
+            _, conv, bn, ds = item
+            ds_rec = None
+            res = block_in
+            if ds is not None:
+                res, _, ds_rec = run_unit(ds[0], ds[1], False, block_in, block_thw)
+            cur, thw, rec = run_unit(conv, bn, True, cur, thw, residual=res)
+            tape.append(("block_last", rec, ds_rec))
+    return cur, thw, tape
+
+
+def trunk_backward(tape, dz, grads):
+    """dz bf16 grad of the trunk output; fills `grads[param] = tensor`."""
+
+    def unit_bwd(rec, dz_in, relu, want_dres, dgrad_residual=None, need_dx=True):
+        dy, dres, dg, db = L.bn_bwd(dz_in, rec.y, rec.z, rec.sv, rec.bn.weight, relu=relu, want_dres=want_dres)
+        if rec.bn.weight.requires_grad:
+            grads[rec.bn.weight], grads[rec.bn.bias] = dg, db
+        if rec.conv.weight.requires_grad:
+            grads[rec.conv.weight] = L.conv_wgrad(rec.x, dy, rec.geom, rec.conv.weight.shape)
+        dx = None
+        if need_dx and not rec.first:
+            dx = L.conv_dgrad(dy, rec.geom, rec.wd, residual=dgrad_residual)
+        return dx, dres
+
+    i = len(tape) - 1
+    cur = dz
+    while i >= 0:
+        kind = tape[i][0]
+        if kind == "unit":
+            cur, _ = unit_bwd(tape[i][1], cur, tape[i][1].relu, False)
+            i -= 1
+        elif kind == "block_last":
+            _, rec, ds_rec = tape[i]
+            # find this block's inner units (between block_begin and here)
+            j = i - 1
+            inner = []
+            while tape[j][0] != "block_begin":
+                inner.append(tape[j][1])
+                j -= 1
+            dmain, dres = unit_bwd(rec, cur, True, True)
+            for r in inner[:-1]:
+                dmain, _ = unit_bwd(r, dmain, r.relu, False)
+            skip = dres
+            if ds_rec is not None:
+                skip, _ = unit_bwd(ds_rec, dres, False, False)
+            firstu = inner[-1] if inner else None
+            if firstu is not None:
+                cur, _ = unit_bwd(firstu, dmain, firstu.relu, False, dgrad_residual=skip)
+            else:
+                raise RuntimeError("block without inner units")
+            i = j - 1
+        else:
+            i -= 1
+    return cur

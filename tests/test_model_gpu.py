@@ -1,0 +1,280 @@
+"""Parity of the HIP training step (pig API -> peppa_amd) against the CPU oracle, same weights and
+same synthetic clips.
+
+What is asserted, and why these tolerances (DESIGN.md "Numerics"):
+  * per-stage parity (stem, each residual block) with the oracle's own activation as input
+    ("teacher forced"): forward <= 2.5 % relative L2 (measured 0.5-0.7 %, identical to torch's bf16
+    autocast of the same block); backward <= 16-18 %: ReLU masks of near-zero bf16 activations flip
+    and BatchNorm's backward subtracts two large projections, so torch's own bf16 autocast of one
+    oracle block is 9-12 % off fp32 for dx and 10-13 % for dW (measured in the build container);
+    the HIP path measures the same 9-12 %.  Each primitive is checked tightly in
+    test_kernels_gpu.py; this test guards the composition (a dropped residual or a wrong operand
+    shows up as >> 20 %);
+  * end to end, a random-init r2plus1d_18 with train-mode BatchNorm amplifies any bf16 rounding by
+    ~1.1x per conv unit (torch's own bf16 autocast of the ORACLE reaches cosine 0.984 / trunk error
+    27 % on this input), so the full-depth check uses that autocast run as the yardstick: the HIP
+    path must be as close to the fp32 oracle as torch's bf16 run is (x1.5 slack);
+  * the audio tower (LayerNorm, no BatchNorm) is well conditioned: cosine >= 0.999, max-abs <= 2e-2.
+"""
+import copy
+import warnings
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore")
+
+from oracle import model as O
+import pig.models
+import pig.optimization
+import pig.metrics
+from pig.execution import default_config
+from peppa_amd.data import synthetic_batch
+from peppa_amd import video as PV
+from peppa_amd import layers as L
+
+DEV = "cuda"
+
+
+def make_cfg(freeze=False):
+    cfg = copy.deepcopy(default_config)
+    cfg["video"]["pretrained"] = False
+    cfg["audio"]["pretrained"] = False
+    if freeze:
+        cfg["audio"]["freeze_feature_extractor"] = True
+        cfg["audio"]["freeze_encoder_layers"] = 12
+    return cfg
+
+
+def build_pair(cfg, seed=0):
+    torch.manual_seed(seed)
+    ref = O.PeppaPigOracle(cfg, dropout=0.0, layer_drop=0.0)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():  # non-trivial affine parameters so their gradients are exercised
+        for m in ref.modules():
+            if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.LayerNorm, torch.nn.GroupNorm)):
+                m.weight.copy_(1.0 + 0.2 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+    net = pig.models.PeppaPig(cfg)
+    missing, unexpected = net.load_state_dict(ref.state_dict(), strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    return ref, net.to(DEV)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def rb(t):
+    return t.to(torch.bfloat16).float()
+
+
+def to_cl(x, cp):
+    B, C = x.shape[:2]
+    y = x.permute(0, 2, 3, 4, 1).reshape(-1, C)
+    out = torch.zeros(y.shape[0], cp)
+    out[:, :C] = y
+    return out.to(torch.bfloat16).to(DEV)
+
+
+def from_cl(y, B, thw, C):
+    return y.float().cpu()[:, :C].reshape(B, *thw, C).permute(0, 4, 1, 2, 3)
+
+
+def test_video_blocks_teacher_forced():
+    """Every residual block of r2plus1d_18, forward and backward, fed the oracle's own input."""
+    cfg = make_cfg()
+    ref, net = build_pair(cfg)
+    ref.train(); net.train()
+    batch = synthetic_batch(4, 4, 32, 4000)
+    rv, hv = ref.video_encoder.video, net.video_encoder.video
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        x = rv.stem(O.normalize_video(batch.video, "peppa"))
+    worst_f = worst_b = 0.0
+    for li, (rlayer, hlayer) in enumerate(zip((rv.layer1, rv.layer2, rv.layer3, rv.layer4),
+                                              (hv.layer1, hv.layer2, hv.layer3, hv.layer4))):
+        for bi, (rblk, hblk) in enumerate(zip(rlayer, hlayer)):
+            xin = rb(x.detach()).requires_grad_()
+            out = rblk(xin)
+            dout = rb(torch.randn(out.shape, generator=g))
+            for p in rblk.parameters():
+                p.grad = None
+            out.backward(dout)
+            B, C = xin.shape[:2]
+            thw = tuple(xin.shape[2:])
+            with torch.no_grad():
+                z, thw_o, tape = PV.run_plan(PV.VideoResNet.block_plan(hblk), to_cl(xin.detach(), L.cpad(C)), thw, B,
+                                             True, True)
+                grads = {}
+                dx = PV.trunk_backward(tape, to_cl(dout, z.shape[1]), grads)
+            torch.cuda.synchronize()
+            ef = rel(from_cl(z, B, thw_o, out.shape[1]), out)
+            eb = rel(from_cl(dx, B, thw, C), xin.grad)
+            worst_f, worst_b = max(worst_f, ef), max(worst_b, eb)
+            print(f"layer{li + 1}.{bi}: fwd {ef:.4f} dx {eb:.4f}", end="")
+            assert ef < 0.025 and eb < 0.16, (li, bi, ef, eb)
+            for (n, pr), ph in zip(rblk.named_parameters(), hblk.parameters()):
+                e = rel(grads[ph], pr.grad)
+                assert e < 0.18, (li, bi, n, e)
+            print("  params ok")
+            x = out.detach()
+    print("worst fwd", worst_f, "worst dx", worst_b)
+
+
+def test_video_stem_teacher_forced():
+    cfg = make_cfg()
+    ref, net = build_pair(cfg)
+    ref.train(); net.train()
+    batch = synthetic_batch(2, 4, 32, 4000)
+    rv, hv = ref.video_encoder.video, net.video_encoder.video
+    out = rv.stem(O.normalize_video(batch.video, "peppa"))
+    dout = rb(torch.randn(out.shape, generator=torch.Generator().manual_seed(2)))
+    out.backward(dout)
+    with torch.no_grad():
+        xg = batch.video.to(DEV)
+        cur = torch.empty(xg.numel() // 3, 8, dtype=torch.bfloat16, device=DEV)
+        from peppa_amd import hip as H
+        H.video_normalize_ndhwc(xg, cur, *PV.VIDEO_STATS["peppa"])
+        z, thw, tape = PV.run_plan(hv.stem_plan(), cur, tuple(batch.video.shape[2:]), 2, True, True, first=True)
+        grads = {}
+        PV.trunk_backward(tape, to_cl(dout, 64), grads)
+    torch.cuda.synchronize()
+    assert rel(from_cl(z, 2, thw, 64), out) < 0.02
+    for pr, ph in zip(rv.stem.parameters(), hv.stem.parameters()):
+        assert rel(grads[ph], pr.grad) < 0.12
+
+
+@pytest.mark.parametrize("freeze", [False, True])
+def test_audio_tower_parity(freeze):
+    """wav2vec2 + attention pooling + projection: forward and (smooth-objective) gradients."""
+    cfg = make_cfg(freeze)
+    ref, net = build_pair(cfg)
+    ref.train(); net.train()
+    batch = synthetic_batch(4, 4, 32, 4000)
+    R = torch.randn(4, 512, generator=torch.Generator().manual_seed(1))
+    Ar = ref.encode_audio(batch.audio)
+    (Ar * R).sum().backward()
+    A = net.encode_audio(batch.audio.to(DEV))
+    (A * R.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    cos = F.cosine_similarity(A.detach().cpu(), Ar.detach(), dim=1).min().item()
+    err = (A.detach().cpu() - Ar.detach()).abs().max().item()
+    print(f"audio embeddings: min cosine {cos:.6f}, max abs err {err:.4g}")
+    assert cos >= 0.999 and err <= 2e-2
+    refp = dict(ref.audio_encoder.named_parameters())
+    rows = []
+    for name, p in net.audio_encoder.named_parameters():
+        pr = refp[name]
+        if pr.grad is None:
+            assert p.grad is None, f"{name}: unexpected gradient"
+            continue
+        assert p.grad is not None and p.grad.shape == pr.grad.shape, name
+        rows.append((rel(p.grad, pr.grad), pr.grad.norm().item(), name))
+    rows.sort(reverse=True)
+    for e, n, name in rows[:10]:
+        print(f"  grad rel err {e:.4f} |g|={n:.2e} {name}")
+    gmax = max(n for _, n, _ in rows)
+    # tensors whose true gradient is (analytically) ~0, e.g. k_proj.bias, only need to be small
+    bad = [(e, name) for e, n, name in rows if (n > 1e-4 * gmax and e > 0.08)]
+    assert not bad, bad[:8]
+    tiny = [(name, n) for e, n, name in rows if n <= 1e-4 * gmax]
+    hp = dict(net.audio_encoder.named_parameters())
+    for name, n in tiny:
+        assert hp[name].grad.norm().item() < 1e-2 * gmax, name
+    if freeze:
+        fe = net.audio_encoder.audio.feature_extractor
+        assert all(p.grad is None for p in fe.parameters())
+        assert net.audio_encoder.audio.encoder.transformer.layers[0].attention.q_proj.weight.grad is None
+        assert net.audio_encoder.audio.encoder.transformer.pos_conv_embed.conv.weight_v.grad is not None
+        assert net.audio_encoder.audio.encoder.feature_projection.projection.weight.grad is not None
+
+
+def test_training_step_end_to_end_with_bf16_yardstick():
+    cfg = make_cfg()
+    ref, net = build_pair(cfg)
+    ref.train(); net.train()
+    batch = synthetic_batch(4, 4, 32, 4000)
+    with torch.no_grad():
+        V32, A32 = ref.encode_video(batch.video), ref.encode_audio(batch.audio)
+        sd = copy.deepcopy(ref.state_dict())  # autocast run must not see updated BN buffers
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            V16 = ref.encode_video(batch.video).float()
+        ref.load_state_dict(sd)
+        loss32 = ref.loss(V32, A32).item()
+    gb = batch.to(DEV)
+    loss = net.training_step(gb, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(net.video_encoder.video.stem[1].running_mean, ref.video_encoder.video.stem[1].running_mean) < 0.05
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    used = [n for n, p in net.named_parameters() if not n.startswith("video_encoder.video.fc")]
+    assert all(dict(net.named_parameters())[n].grad is not None for n in used)
+    assert net.video_encoder.video.fc.weight.grad is None  # unused parameter
+    with torch.no_grad():
+        Vh = net.encode_video(gb.video).cpu()
+        Ah = net.encode_audio(gb.audio).cpu()
+    yard = 1 - F.cosine_similarity(V16, V32, dim=1).min().item()
+    ours = 1 - F.cosine_similarity(Vh, V32, dim=1).min().item()
+    print(f"video 1-cos: HIP {ours:.5f} vs torch bf16 autocast of the oracle {yard:.5f}; loss {loss.item():.5f} / {loss32:.5f}")
+    assert (Vh.norm(dim=1) - 1).abs().max() < 1e-4 and (Ah.norm(dim=1) - 1).abs().max() < 1e-4
+    assert ours <= 1.5 * yard + 2e-3
+    assert F.cosine_similarity(Ah, A32, dim=1).min().item() >= 0.999
+    assert abs(loss.item() - loss32) <= 0.05  # hinge loss on N=4 noisy video embeddings
+
+
+def test_optimizer_step_matches_reference_rule():
+    cfg = make_cfg()
+    ref, net = build_pair(cfg, seed=3)
+    gb = synthetic_batch(2, 4, 32, 4000, seed=7).to(DEV)
+    optim = net.configure_optimizers()
+    assert isinstance(optim, pig.optimization.BertAdam)
+    names = [n for n, _ in net.named_parameters()]
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    cpu_params = [before[n].cpu().clone() for n in names]
+    st = {}
+    for step in range(2):
+        optim.zero_grad()
+        loss = net.training_step(gb, step)
+        loss.backward()
+        grads = [p.grad.detach().cpu().clone() if p.grad is not None else None for p in net.parameters()]
+        optim.step()
+        O.bertadam_step(cpu_params, grads, st, **{k: cfg["optimizer"][k] for k in ("lr", "warmup", "t_total")})
+        torch.cuda.synchronize()
+        for n, p, pc in zip(names, net.parameters(), cpu_params):
+            d = (p.detach().cpu() - pc).abs().max().item()
+            assert d <= 1e-6 + 1e-5 * pc.abs().max().item(), (n, step, d)
+        if step == 0:  # warmup_linear(0) == 0: the first step leaves the weights untouched
+            assert all(torch.equal(p.detach(), before[n]) for n, p in net.named_parameters())
+    moved = sum((p.detach() != before[n]).any().item() for n, p in net.named_parameters())
+    assert moved > 100
+
+
+def test_api_surface_and_errors():
+    cfg = make_cfg()
+    for key, field in (("video", "pooling"), ("audio", "pooling"), ("video", "version")):
+        bad = copy.deepcopy(cfg)
+        bad[key][field] = "nope"
+        with pytest.raises(ValueError):
+            pig.models.PeppaPig(bad)
+    net = pig.models.PeppaPig(cfg)
+    with pytest.raises(Exception):  # CPU tensors are rejected: no fallback
+        net.encode_audio(torch.zeros(1, 1, 4000))
+    net = net.to(DEV).eval()
+    b = synthetic_batch(2, 4, 32, 4000).to(DEV)
+    with torch.no_grad():
+        out = net(b)
+        out2 = net(b)
+    assert out.video.shape == (2, 512) and out.audio.shape == (2, 512)
+    assert torch.equal(out.video, out2.video)  # eval mode: running statistics, deterministic
+    feats, _ = net.audio_encoder.audio.extract_features(b.audio.squeeze(1))
+    assert feats.shape == (2, 12, 512)
+    acc = pig.metrics.triplet_accuracy(out.audio, out.video, out.video.flip(0))
+    ref_acc = O.triplet_accuracy(out.audio.cpu(), out.video.cpu(), out.video.flip(0).cpu())
+    assert torch.equal(acc.cpu(), ref_acc)
+    cm = pig.loss.cosine_matrix(out.video, out.audio).cpu()
+    assert (cm - O.cosine_matrix(out.video.cpu(), out.audio.cpu())).abs().max() < 1e-5
+    tri = pig.triplet.score_triplets(out.video.repeat(4, 1), out.audio.repeat(4, 1), torch.tensor([1., 1, 2, 2, 1, 1, 2, 2]), n_samples=3)
+    assert tri.shape == (3,)
