@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Headline benchmark: clip-pairs/sec of the PeppaPig training step (video fwd + audio fwd + triplet
+loss + backward + gradient all-reduce + BertAdam) on hparams_base shapes (BASELINE.json configs[1]):
+B=64 clips per GPU of 16x112x112 video + 2.3 s @ 16 kHz audio, bf16 compute, synthetic data,
+random-init weights.  One process per GPU (torch.distributed / RCCL); weak scaling.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+import warnings
+
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+GF_TRAIN_PER_PAIR = 340.0e9      # SURVEY 8d / BASELINE.md: 3 x (81.04 + 32.30) GFLOP
+MFMA_BF16_PEAK = 2.5e15          # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=112)
+    ap.add_argument("--samples", type=int, default=36800)
+    ap.add_argument("--config", default=os.path.join(ROOT, "hparams_base.yaml"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, args):
+    """The CPU oracle (fp32, torch CPU threads) on a bounded sample of the same workload."""
+    from oracle import model as O
+    torch.manual_seed(0)
+    net = O.PeppaPigOracle(cfg, dropout=0.0, layer_drop=0.0).train()
+    v, a = O.synthetic_batch(args.cpu_batch, args.frames, args.size, args.samples)
+    params = [p for p in net.parameters()]
+    state = {}
+    t0 = time.perf_counter()
+    loss = net.training_loss(v, a)
+    loss.backward()
+    with torch.no_grad():
+        O.bertadam_step(params, [p.grad for p in params], state, **{k: cfg["optimizer"][k] for k in ("lr", "warmup", "t_total")})
+    dt = time.perf_counter() - t0
+    return {"value": args.cpu_batch / dt, "unit": "clip-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 full training step (fwd+loss+bwd+BertAdam) of the fp32 CPU oracle at batch {args.cpu_batch}, "
+                      f"{args.frames}x{args.size}x{args.size} video + {args.samples} audio samples, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import yaml
+    import pig.models
+    from peppa_amd import hip as H
+    from peppa_amd.data import synthetic_batch
+    from peppa_amd.dist import GradBuckets
+    cfg = yaml.safe_load(open(args.config))
+    cfg["video"]["pretrained"] = False   # weights cannot be downloaded offline: random init, same architecture
+    cfg["audio"]["pretrained"] = False
+    torch.manual_seed(0)
+    net = pig.models.PeppaPig(cfg).to(dev).train()
+    optim = net.configure_optimizers()
+    batch = synthetic_batch(args.batch, args.frames, args.size, args.samples, seed=1234 + rank).to(dev)
+    buckets = None
+    if world > 1:
+        audio = list(net.audio_encoder.parameters())
+        video = [p for n, p in net.video_encoder.named_parameters() if not n.startswith("video.fc")]
+        buckets = GradBuckets([("audio", audio), ("video", video)], dev)
+
+    def step(i):
+        optim.zero_grad(set_to_none=True)
+        loss = net.training_step(batch, i)
+        loss.backward()
+        if buckets is not None:
+            buckets.finish()
+        optim.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    H.PROFILE.clear()
+    H.PROFILE_ON = True
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    H.PROFILE_ON = False
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+    # dominant kernel: HIP events recorded around its launches inside the timed region
+    roof = H.profile_summary()
+    roof_obj = None
+    if roof:
+        flops, secs, n, name = roof
+        ach = flops / secs / 1e12
+        roof_obj = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                    "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4), "traffic": None, "kernel": name,
+                    "launches": n, "avg_us": round(secs / n * 1e6, 1)}
+    out = {
+        "metric": "clip-pairs/sec (A+V encode + triplet loss), hparams_base", "value": round(value, 2),
+        "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"hparams_base.yaml training step, {args.frames}x{args.size}x{args.size} video + "
+                               f"{args.samples / 16000:.1f} s@16kHz audio, batch {args.batch}/GPU (BASELINE configs[1])",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                   "step_tflops": round(GF_TRAIN_PER_PAIR * world * args.batch / (ms * 1e-3) / 1e12, 1),
+                   "loss": round(float(loss.item()), 5)},
+        "roofline": roof_obj,
+    }
+    if world > 1:
+        dist.destroy_process_group()
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, args)
+        except Exception as e:  # report, never hide
+            out["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+"""Data-parallel pieces (new work: the reference is single-GPU).
+
+One process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI) or "gloo" (CPU tests):
+  * `gather_embeddings`: ONE all-gather of the concatenated [V_local; A_local] (2 x B x 512 fp32,
+    256 KiB per rank -- latency bound) so every rank evaluates the triplet loss on the global
+    N = world x B negative pool.  Backward needs no collective: every rank holds the same global
+    dV/dA and keeps its own rows.
+  * `GradBuckets`: gradients are copied into a few large flat fp32 buckets (one per encoder, sized
+    for 7 x 153 GB/s point-to-point xGMI links rather than for many small NVSwitch-style calls) and
+    all-reduced with SUM on a side stream as soon as a bucket is complete, overlapping the other
+    encoder's backward.  SUM, not mean: each rank's loss is already the global mean and its backward
+    only covers the local clips ("all-gather gradient routing").
+BatchNorm uses per-rank statistics (documented deviation from a single-process N=512 batch).
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _GatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, V, A):
+        world, rank = dist.get_world_size(), dist.get_rank()
+        B, D = V.shape
+        local = torch.cat([V, A], dim=0).contiguous()            # plumbing: pack for one collective
+        out = torch.empty(world * 2 * B, D, dtype=V.dtype, device=V.device)
+        dist.all_gather_into_tensor(out, local)
+        out = out.view(world, 2, B, D)
+        ctx.rank, ctx.B = rank, B
+        return out[:, 0].reshape(world * B, D), out[:, 1].reshape(world * B, D)
+
+    @staticmethod
+    def backward(ctx, dVg, dAg):
+        r, B = ctx.rank, ctx.B
+        return dVg[r * B:(r + 1) * B].contiguous(), dAg[r * B:(r + 1) * B].contiguous()
+
+
+def gather_embeddings(V, A):
+    """(B,D),(B,D) local -> (world*B,D),(world*B,D) global, rank-major; identity when not distributed."""
+    if not is_dist():
+        return V, A
+    return _GatherFn.apply(V, A)
+
+
+class GradBuckets:
+    """Flat gradient buckets with per-bucket asynchronous all-reduce (SUM)."""
+
+    def __init__(self, named_groups, device):
+        """named_groups: [(name, [params])]; params without grad at step time are skipped (zeros)."""
+        self.buckets = []
+        self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        for name, params in named_groups:
+            params = [p for p in params if p.requires_grad]
+            total = sum(p.numel() for p in params)
+            flat = torch.zeros(total, dtype=torch.float32, device=device)
+            views, off = [], 0
+            for p in params:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self.buckets.append(dict(name=name, params=params, flat=flat, views=views, pending=0, work=None))
+        self._hooks = []
+        self._by_param = {}
+        for b in self.buckets:
+            for p in b["params"]:
+                self._by_param[p] = b
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.reset()
+
+    def reset(self):
+        for b in self.buckets:
+            b["pending"] = len(b["params"])
+            b["work"] = None
+
+    def _on_grad(self, p):
+        b = self._by_param[p]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        grads = [p.grad for p in b["params"]]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                torch._foreach_copy_(b["views"], grads)          # plumbing: pack
+                if is_dist():
+                    b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            torch._foreach_copy_(b["views"], grads)
+            if is_dist():
+                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """Wait for the collectives and point every p.grad at its reduced bucket view."""
+        for b in self.buckets:
+            if b["pending"] > 0:  # parameters that received no gradient this step (unused / frozen path)
+                missing = [p for p in b["params"] if p.grad is None]
+                if len(missing) != b["pending"]:
+                    raise RuntimeError(f"bucket {b['name']}: inconsistent gradient arrival")
+                for p in missing:
+                    self._by_param[p]  # keep mapping; contribute zeros
+                for p, v in zip(b["params"], b["views"]):
+                    if p.grad is None:
+                        v.zero_()
+                    else:
+                        v.copy_(p.grad)
+                if is_dist():
+                    b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+            if b["work"] is not None:
+                b["work"].wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        for b in self.buckets:
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+        self.reset()

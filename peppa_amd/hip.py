@@ -51,6 +51,35 @@ def gather_conv(mode, R, G, k, s, p, cg, cstride):
     return g
 
 
+# ---- optional in-process kernel timing (bench.py roofline): HIP events on the launch stream ----------
+PROFILE_ON = False
+PROFILE = {}
+PROFILE_MIN_FLOP = 2.0e10
+_MODE_NAMES = {DENSE: "dense", CONV_FWD: "conv_fwd", CONV_DGRAD: "conv_dgrad"}
+
+
+def _profiled(key, flops, fn):
+    if not PROFILE_ON or flops < PROFILE_MIN_FLOP:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    PROFILE.setdefault(key, []).append((e0, e1, flops))
+
+
+def profile_summary():
+    """(flops, seconds, launches, name) of the kernel family with the largest total time, or None."""
+    torch.cuda.synchronize()
+    best = None
+    for key, recs in PROFILE.items():
+        secs = sum(a.elapsed_time(b) for a, b, _ in recs) * 1e-3
+        fl = sum(f for _, _, f in recs)
+        if best is None or secs > best[1]:
+            best = (fl, secs, len(recs), key)
+    return best
+
+
 def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NONE, residual=None, ldr=0,
           Cpre=None, colstats=None, ldstat=0, nbatch=1, inner=1, a_s=(0, 0), b_s=(0, 0), c_s=(0, 0),
           bias_s=(0, 0)):
@@ -67,7 +96,8 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
     d.b_s0, d.b_s1 = b_s
     d.c_s0, d.c_s1 = c_s
     d.bias_s0, d.bias_s1 = bias_s
-    call("pp_igemm", C.byref(d), _s())
+    _profiled(f"igemm_kernel<{_MODE_NAMES[g.mode]}> N={N} K={K}", 2.0 * M * N * K * nbatch,
+              lambda: call("pp_igemm", C.byref(d), _s()))
 
 
 def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0):
@@ -75,7 +105,8 @@ def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=
     d.M, d.Ni, d.Kj, d.g = M, Ni, Kj, g
     d.X, d.dY, d.ldy, d.dW, d.ldw = _p(X, bf16), _p(dY, bf16), ldy, _p(dW, f32), ldw
     d.msplit, d.nbatch, d.x_s, d.dy_s, d.dw_s = msplit, nbatch, x_s, dy_s, dw_s
-    call("pp_wgrad", C.byref(d), _s())
+    _profiled(f"wgrad_kernel<{_MODE_NAMES[g.mode]}> Ni={Ni} Kj={Kj}", 2.0 * M * Ni * Kj * nbatch,
+              lambda: call("pp_wgrad", C.byref(d), _s()))
 
 
 # ---- weight preparation ----------------------------------------------------------------------

@@ -15,6 +15,7 @@ from .loss import TripletLoss
 from . import metrics as _metrics
 from . import optimization as opt
 from .data import ClipBatch
+from .dist import gather_embeddings
 from .triplet import TripletBatch as EmbeddingTripletBatch, score_triplets
 from .transforms import SwapCT  # noqa: F401  (API surface)
 
@@ -273,6 +274,7 @@ class PeppaPig(_Base):
     def training_step(self, batch, batch_idx):
         V_ = self.encode_video(batch.video)
         A_ = self.encode_audio(batch.audio)
+        V_, A_ = gather_embeddings(V_, A_)  # data-parallel: global negative pool (identity on one GPU)
         loss = self.loss(V_, A_)
         # the reference logs loss.item() (a host sync per step, pig/models.py:264); log the tensor instead
         self.log("train_loss", loss.detach(), prog_bar=True)
