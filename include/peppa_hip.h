@@ -77,6 +77,8 @@ typedef struct pp_wgrad_desc {
   int msplit;                     /* 0 = choose automatically */
   int nbatch;                     /* grouped conv: groups */
   long long x_s, dy_s, dw_s;      /* per-batch offsets (elements) */
+  float* dbias;                   /* optional: dbias[Ni] += column sums of dY (zeroed by the caller) */
+  long long dbias_s;
 } pp_wgrad_desc;
 int pp_wgrad(const pp_wgrad_desc* d, pp_stream_t s);
 
@@ -113,7 +115,8 @@ int pp_video_normalize_ndhwc(const float* x, void* out, int B, int T, int H, int
 int pp_bn_finalize(const float* partials, int nblk, int ldstat, long long count, int C, int Cp,
                    const float* gamma, const float* beta, float eps, float momentum,
                    float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
-                   float* shift, pp_stream_t s);
+                   float* shift, float* ws /* optional 64*2*ldstat floats: parallel first-level reduce */,
+                   pp_stream_t s);
 /* eval mode: scale/shift from the running statistics */
 int pp_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, int Cp, float* scale, float* shift,

@@ -36,7 +36,8 @@ class WGradDesc(C.Structure):
         ("M", C.c_int), ("Ni", C.c_int), ("Kj", C.c_int), ("g", Gather),
         ("X", C.c_void_p), ("dY", C.c_void_p), ("ldy", C.c_int), ("dW", C.c_void_p), ("ldw", C.c_int),
         ("msplit", C.c_int), ("nbatch", C.c_int),
-        ("x_s", C.c_longlong), ("dy_s", C.c_longlong), ("dw_s", C.c_longlong)]
+        ("x_s", C.c_longlong), ("dy_s", C.c_longlong), ("dw_s", C.c_longlong),
+        ("dbias", C.c_void_p), ("dbias_s", C.c_longlong)]
 
 
 class TensorList(C.Structure):
@@ -61,7 +62,7 @@ SIGNATURES = {
     "pp_transpose_bf16": [P, L, I, P, L, I, I, I, I, I, L, L, I, P],
     "pp_fill_f32": [P, F, L, P],
     "pp_video_normalize_ndhwc": [P, P, I, I, I, I, C.POINTER(F), C.POINTER(F), P],
-    "pp_bn_finalize": [P, I, I, L, I, I, P, P, F, F, P, P, P, P, P, P, P],
+    "pp_bn_finalize": [P, I, I, L, I, I, P, P, F, F, P, P, P, P, P, P, P, P],
     "pp_colstats_bf16": [P, L, I, P, I, P],
     "pp_bn_eval_affine": [P, P, P, P, F, I, I, P, P, P],
     "pp_bn_apply": [P, P, P, P, I, P, L, I, P],

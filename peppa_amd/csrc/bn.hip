@@ -51,6 +51,29 @@ __global__ __launch_bounds__(256) void colstats_kernel(const bfraw* __restrict__
   });
 }
 
+// first level of the statistics reduction: [nblk][2][ld] -> [nslice][2][ld]
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ partials, int nblk, int ld,
+                                                              int per_slice, float* __restrict__ out) {
+  __shared__ float s1s[16][17], s2s[16][17];
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int b0 = blockIdx.y * per_slice, b1 = min(nblk, b0 + per_slice);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < ld)
+    for (int b = b0 + part; b < b1; b += 16) {
+      s1 += partials[((long long)b * 2 + 0) * ld + c];
+      s2 += partials[((long long)b * 2 + 1) * ld + c];
+    }
+  s1s[part][cl] = s1;
+  s2s[part][cl] = s2;
+  __syncthreads();
+  if (part == 0 && c < ld) {
+    for (int q = 1; q < 16; ++q) { s1 += s1s[q][cl]; s2 += s2s[q][cl]; }
+    out[((long long)blockIdx.y * 2 + 0) * ld + c] = s1;
+    out[((long long)blockIdx.y * 2 + 1) * ld + c] = s2;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int ldstat,
                                                           double count, int C, int Cp, const float* gamma,
                                                           const float* beta, float eps, float momentum,
@@ -226,8 +249,16 @@ extern "C" int pp_colstats_bf16(const void* y, long long M, int Cp, float* parti
 
 extern "C" int pp_bn_finalize(const float* partials, int nblk, int ldstat, long long count, int C, int Cp,
                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                              float* running_var, float* mean, float* rstd, float* scale, float* shift, pp_stream_t s) {
+                              float* running_var, float* mean, float* rstd, float* scale, float* shift, float* ws,
+                              pp_stream_t s) {
   PP_CHECK_ARG(C > 0 && Cp >= C && ldstat >= Cp && nblk > 0 && count > 0, "pp_bn_finalize: bad sizes");
+  if (ws && nblk > 256) {  // two-level reduction: 64 slices in parallel, then the finalize over 64 rows
+    const int nslice = 64, per_slice = (nblk + nslice - 1) / nslice;
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((ldstat + 15) / 16, nslice), dim3(256), 0, (hipStream_t)s, partials, nblk,
+                       ldstat, per_slice, ws);
+    partials = ws;
+    nblk = nslice;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 15) / 16), dim3(256), 0, (hipStream_t)s, partials, nblk, ldstat,
                      (double)count, C, Cp, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift);
   PP_LAUNCH_CHECK();

@@ -96,17 +96,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bfraw* __restrict__ d
       }
     }
   }
-  if (r0 < r1) {
+  // combine the block's 4 waves in LDS, then one atomic per channel per block
+  __shared__ float red[2][4][64 * 8 * LN_MAXC];
+  const int w = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-      const int ch = lane + 64 * c;
-      if (ch < nch)
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          atomicAdd(dgamma + ch * 8 + q, ag[c][q]);
-          atomicAdd(dbeta + ch * 8 + q, ab[c][q]);
-        }
-    }
+      for (int q = 0; q < 8; ++q) {
+        red[0][w][ch * 8 + q] = ag[c][q];
+        red[1][w][ch * 8 + q] = ab[c][q];
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) {
+    atomicAdd(dgamma + i, red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
+    atomicAdd(dbeta + i, red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
   }
 }
 
@@ -169,25 +175,31 @@ constexpr int C0 = 512, K0 = 10, S0 = 5, TT0 = 64;  // channels, kernel, stride,
 template <class F>
 __device__ __forceinline__ void conv0_tile(const float* __restrict__ wave, int L, int T0, const float* __restrict__ w,
                                            float* xs, F f) {
-  // grid: (ceil(T0/TT0), B); thread handles channels 2*tid, 2*tid+1
-  const int b = blockIdx.y, t0 = blockIdx.x * TT0;
-  const int nt = min(TT0, T0 - t0);
-  const int nx = (nt - 1) * S0 + K0;
-  for (int i = threadIdx.x; i < nx; i += 256) xs[i] = wave[(long long)b * L + (long long)t0 * S0 + i];
-  __syncthreads();
+  // grid: (tiles-per-block groups, B); each block walks tiles blockIdx.x, +gridDim.x, ... so that the
+  // per-thread reductions of the callers end in few atomics; thread handles channels 2*tid, 2*tid+1
+  const int b = blockIdx.y;
   const int c = threadIdx.x * 2;
   float w0[K0], w1[K0];
 #pragma unroll
   for (int k = 0; k < K0; ++k) { w0[k] = w[c * K0 + k]; w1[k] = w[(c + 1) * K0 + k]; }
-  for (int t = 0; t < nt; ++t) {
-    float y0 = 0.f, y1 = 0.f;
+  const int ntiles = (T0 + TT0 - 1) / TT0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int t0 = tile * TT0;
+    const int nt = min(TT0, T0 - t0);
+    const int nx = (nt - 1) * S0 + K0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nx; i += 256) xs[i] = wave[(long long)b * L + (long long)t0 * S0 + i];
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      float y0 = 0.f, y1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < K0; ++k) {
-      const float xv = xs[t * S0 + k];
-      y0 += w0[k] * xv;
-      y1 += w1[k] * xv;
+      for (int k = 0; k < K0; ++k) {
+        const float xv = xs[t * S0 + k];
+        y0 += w0[k] * xv;
+        y1 += w1[k] * xv;
+      }
+      f(b, t0 + t, t, c, y0, y1);
     }
-    f(b, t0 + t, t, c, y0, y1);
   }
 }
 
@@ -345,8 +357,8 @@ extern "C" int pp_layernorm_fwd(const void* x, const float* gamma, const float* 
 extern "C" int pp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int rows, int D, pp_stream_t s) {
   PP_CHECK_ARG(rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC, "pp_layernorm_bwd: D=%d unsupported", D);
-  int waves = (rows + 7) / 8;  // ~8 rows per wave
-  if (waves > 4096) waves = 4096;
+  int waves = (rows + 7) / 8;  // >= 8 rows per wave, at most 512 waves (128 workgroups of atomics)
+  if (waves > 512) waves = 512;
   const int rows_per_wave = (rows + waves - 1) / waves;
   waves = (rows + rows_per_wave - 1) / rows_per_wave;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, S_, (const bfraw*)dy, (const bfraw*)x, gamma, mean,
@@ -371,13 +383,20 @@ extern "C" int pp_softmax_bwd(const float* dP, int lds, const void* P, int ldp, 
   return PP_OK;
 }
 
+static int conv0_red_blocks(int T0, int B) {
+  // enough workgroups to fill 256 CUs a few times over, few enough that the final atomics stay cheap
+  const int ntiles = (T0 + TT0 - 1) / TT0;
+  int per_b = (1024 + B - 1) / B;
+  if (per_b > ntiles) per_b = ntiles;
+  return per_b < 1 ? 1 : per_b;
+}
 static int conv0_check(int B, int L, int T0, const char* who) {
   PP_CHECK_ARG(B > 0 && L >= K0 && T0 == (L - K0) / S0 + 1, "%s: T0=%d does not match L=%d", who, T0, L);
   return PP_OK;
 }
 extern "C" int pp_conv0_stats(const float* wave, int B, int L, int T0, const float* w, float* stats, pp_stream_t s) {
   if (int rc = conv0_check(B, L, T0, "pp_conv0_stats")) return rc;
-  hipLaunchKernelGGL(conv0_stats_kernel, dim3((T0 + TT0 - 1) / TT0, B), dim3(256), 0, S_, wave, L, T0, w, stats);
+  hipLaunchKernelGGL(conv0_stats_kernel, dim3(conv0_red_blocks(T0, B), B), dim3(256), 0, S_, wave, L, T0, w, stats);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -393,7 +412,7 @@ extern "C" int pp_conv0_bwd_reduce(const float* wave, int B, int L, int T0, cons
                                    const float* gamma, const float* beta, float eps, const void* dout, float* red,
                                    pp_stream_t s) {
   if (int rc = conv0_check(B, L, T0, "pp_conv0_bwd_reduce")) return rc;
-  hipLaunchKernelGGL(conv0_bwd_reduce_kernel, dim3((T0 + TT0 - 1) / TT0, B), dim3(256), 0, S_, wave, L, T0, w, stats, gamma, beta,
+  hipLaunchKernelGGL(conv0_bwd_reduce_kernel, dim3(conv0_red_blocks(T0, B), B), dim3(256), 0, S_, wave, L, T0, w, stats, gamma, beta,
                      eps, (const bfraw*)dout, red);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -402,7 +421,7 @@ extern "C" int pp_conv0_bwd_apply(const float* wave, int B, int L, int T0, const
                                   const float* gamma, const float* beta, float eps, const void* dout, const float* red,
                                   float* dw, float* dgamma, float* dbeta, pp_stream_t s) {
   if (int rc = conv0_check(B, L, T0, "pp_conv0_bwd_apply")) return rc;
-  hipLaunchKernelGGL(conv0_bwd_apply_kernel, dim3((T0 + TT0 - 1) / TT0, B), dim3(256), 0, S_, wave, L, T0, w, stats, gamma, beta,
+  hipLaunchKernelGGL(conv0_bwd_apply_kernel, dim3(conv0_red_blocks(T0, B), B), dim3(256), 0, S_, wave, L, T0, w, stats, gamma, beta,
                      eps, (const bfraw*)dout, red, dw, dgamma, dbeta);
   PP_LAUNCH_CHECK();
   return PP_OK;

@@ -116,6 +116,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const pp_wgrad_desc p, const
 #pragma unroll
   for (int a = 0; a < WI; ++a) acc[a][0] = acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // optional bias gradient (column sums of dY), taken from the P tiles this block stages anyway
+  const bool do_bias = p.dbias != nullptr && jb == 0;
+  float bsum[NPI][8];
+#pragma unroll
+  for (int it = 0; it < NPI; ++it)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bsum[it][q] = 0.f;
+
   uint4 rq[2], rp[NPI];
   rq[0] = load_q(m_begin + qrow);
   rq[1] = load_q(m_begin + 16 + qrow);
@@ -132,6 +140,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const pp_wgrad_desc p, const
       const int cid = tid + 256 * it;
       const int row = cid / (2 * WI), ch = cid % (2 * WI);
       if (row < MS) *(uint4*)(Pt + row * PS + ch * 16) = rp[it];
+      if (do_bias) {
+        float f[8];
+        unpack8(rp[it], f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bsum[it][q] += f[q];
+      }
     }
     __syncthreads();
     const int mn = mb + MS;
@@ -152,6 +166,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const pp_wgrad_desc p, const
     __syncthreads();
   }
 
+  if (do_bias) {
+#pragma unroll
+    for (int it = 0; it < NPI; ++it) {
+      const int cid = tid + 256 * it;
+      const int row = cid / (2 * WI), ch = cid % (2 * WI);
+      if (row < MS)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int i = i0 + ch * 8 + q;
+          if (i < p.Ni) atomicAdd(p.dbias + z * p.dbias_s + i, bsum[it][q]);
+        }
+    }
+  }
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
   for (int a = 0; a < WI; ++a)

@@ -100,11 +100,12 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
               lambda: call("pp_igemm", C.byref(d), _s()))
 
 
-def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0):
+def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0, dbias=None, dbias_s=0):
     d = WGradDesc()
     d.M, d.Ni, d.Kj, d.g = M, Ni, Kj, g
     d.X, d.dY, d.ldy, d.dW, d.ldw = _p(X, bf16), _p(dY, bf16), ldy, _p(dW, f32), ldw
     d.msplit, d.nbatch, d.x_s, d.dy_s, d.dw_s = msplit, nbatch, x_s, dy_s, dw_s
+    d.dbias, d.dbias_s = _p(dbias, f32), dbias_s
     _profiled(f"wgrad_kernel<{_MODE_NAMES[g.mode]}> Ni={Ni} Kj={Kj}", 2.0 * M * Ni * Kj * nbatch,
               lambda: call("pp_wgrad", C.byref(d), _s()))
 
@@ -154,9 +155,10 @@ def video_normalize_ndhwc(x, out, mean3, std3):
 
 # ---- batch norm -----------------------------------------------------------------------------------
 def bn_finalize(partials, nblk, ldstat, count, Cn, Cp, gamma, beta, eps, momentum, rmean, rvar, mean, rstd,
-                scale, shift):
+                scale, shift, ws=None):
     call("pp_bn_finalize", _p(partials, f32), nblk, ldstat, count, Cn, Cp, _p(gamma, f32), _p(beta, f32), eps,
-         momentum, _p(rmean, f32), _p(rvar, f32), _p(mean, f32), _p(rstd, f32), _p(scale, f32), _p(shift, f32), _s())
+         momentum, _p(rmean, f32), _p(rvar, f32), _p(mean, f32), _p(rstd, f32), _p(scale, f32), _p(shift, f32),
+         _p(ws, f32), _s())
 
 
 def bn_eval_affine(gamma, beta, rmean, rvar, eps, Cn, Cp, scale, shift):

@@ -141,9 +141,10 @@ def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momen
     if partials is None:  # eval mode: running statistics (no backward through this path)
         H.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, eps, C, Cp, sv.scale, sv.shift)
     else:
+        ws = empty((64, 2, Cp), f32, y) if nblk > 256 else None
         H.bn_finalize(partials, nblk, Cp, count, C, Cp, bn.weight, bn.bias, eps, momentum,
                       bn.running_mean if update_running else None, bn.running_var if update_running else None,
-                      sv.mean, sv.rstd, sv.scale, sv.shift)
+                      sv.mean, sv.rstd, sv.scale, sv.shift, ws)
     z = empty(y.shape, bf16, y)
     H.bn_apply(y, sv.scale, sv.shift, residual, relu, z, y.shape[0], Cp)
     return z, sv
@@ -200,17 +201,16 @@ def linear_dgrad(dy, M, wt, K, *, residual=None):
 def linear_wgrad(x, dy, M, N, K, *, want_bias=True):
     """dW fp32 [N][K], db fp32 [N] from x [M][Kp], dy [M][Np]."""
     Kp, Np = x.shape[1], dy.shape[1]
-    gw = zeros((N, Kp), f32, x)
-    H.wgrad(x, dy, gw, M, N, Kp, H.gather_dense(Kp), Np, Kp)
+    # one zeroed arena for dW and db; the bias gradient is accumulated by the same wgrad launch
+    arena = zeros((N * Kp + (N if want_bias else 0),), f32, x)
+    gw = arena[:N * Kp].view(N, Kp)
+    db = arena[N * Kp:] if want_bias else None
+    H.wgrad(x, dy, gw, M, N, Kp, H.gather_dense(Kp), Np, Kp, dbias=db)
     if Kp != K:
         dw = empty((N, K), f32, x)
         H.copy_2d_f32(gw, Kp, dw, K, N, K)
     else:
         dw = gw
-    db = None
-    if want_bias:
-        db = empty((N,), f32, x)
-        H.colsum_bf16(dy, M, N, Np, db)
     return dw, db
 
 
