@@ -22,13 +22,14 @@ constexpr int BK = 32;
 __device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
 
 struct RowInfo {
-  long long base;
+  int base;          // dense: row offset; conv: offset of (n, bt, bh, bw) in elements (may be "virtual")
+  int nbase;         // conv: n * Gt*Gh*Gw (positions)
   int bt, bh, bw;
   int valid;
 };
 
 template <int WN, int MODE>
-__global__ __launch_bounds__(256) void igemm_kernel(const pp_igemm_desc p, const int nblk_n) {
+__global__ __launch_bounds__(256, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_igemm_desc p, const int nblk_n) {
   constexpr int BN = 16 * WN;
   constexpr int A_BYTES = BM * 64;
   constexpr int B_BYTES = BN * 64;
@@ -37,10 +38,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const pp_igemm_desc p, const
   constexpr int STAT_BYTES = 4 * BN * 2 * 4;
   constexpr int LOOP_BYTES = A_BYTES + B_BYTES;
   constexpr int EPI_BYTES = STG_BYTES + STAT_BYTES;
-  constexpr int SMEM = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
+  constexpr int SMEM = 2 * LOOP_BYTES > EPI_BYTES ? 2 * LOOP_BYTES : EPI_BYTES;
   constexpr int NBI = (BN * 4 + 255) / 256;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-  __shared__ int lut[128];
+  __shared__ int lut[128];      // packed (dt, dh, dw) per tap
+  __shared__ int lut_off[128];  // element offset of the tap inside the source tensor (linear part)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -66,11 +68,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const pp_igemm_desc p, const
         const int dh = t2 % g.kh;
         const int dt = t2 / g.kh;
         e = dt | (dh << 8) | (dw << 16);
+        lut_off[tid] = ((dt * g.Gh + dh) * g.Gw + dw) * g.cstride;
       }
       lut[tid] = e;
     }
     __syncthreads();
   }
+  // stride-1 gathers are linear in the tap: offset = row_base +/- lut_off[tap] (32-bit element offsets;
+  // the host checks that the source tensor has < 2^31 elements)
+  const bool unit_stride = (g.st == 1 && g.sh == 1 && g.sw == 1);
 
   // ---- per-thread row bookkeeping (two A rows per thread) --------------------------------
   const int kq = tid & 3;
@@ -81,7 +87,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const pp_igemm_desc p, const
     ri[i].valid = m < p.M;
     const int mm = ri[i].valid ? m : 0;
     if (MODE == PP_DENSE) {
-      ri[i].base = (long long)mm * g.lda;
+      ri[i].base = mm * g.lda;
+      ri[i].nbase = 0;
       ri[i].bt = ri[i].bh = ri[i].bw = 0;
     } else {
       const int rw = mm % g.Rw;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const pp_igemm_desc p, const
       t /= g.Rh;
       const int rt = t % g.Rt;
       const int n = t / g.Rt;
-      ri[i].base = (long long)n * g.Gt * g.Gh * g.Gw;
+      ri[i].nbase = n * g.Gt * g.Gh * g.Gw;
       if (MODE == PP_CONV_FWD) {
         ri[i].bt = rt * g.st - g.pt;
         ri[i].bh = rh * g.sh - g.ph;
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const pp_igemm_desc p, const
         ri[i].bh = rh + g.ph;
         ri[i].bw = rw + g.pw;
       }
+      ri[i].base = (ri[i].nbase + (ri[i].bt * g.Gh + ri[i].bh) * g.Gw + ri[i].bw) * g.cstride;
     }
   }
   const int sft = g.st == 2, sfh = g.sh == 2, sfw = g.sw == 2;
@@ -115,32 +123,41 @@ __global__ __launch_bounds__(256) void igemm_kernel(const pp_igemm_desc p, const
     const RowInfo& r = ri[i];
     const uint4 zero = make_uint4(0, 0, 0, 0);
     if (MODE == PP_DENSE) {
-      if (r.valid && kcur < p.K) return *(const uint4*)(A + r.base + kcur);
+      if (r.valid && kcur < p.K) return *(const uint4*)(A + (r.base + kcur));
       return zero;
     } else {
       if (!r.valid || tap >= ntaps) return zero;
       const int e = lut[tap];
       const int dt = e & 0xff, dh = (e >> 8) & 0xff, dw = (e >> 16) & 0xff;
-      int gt, gh, gw;
-      bool ok = true;
       if (MODE == PP_CONV_FWD) {
-        gt = r.bt + dt; gh = r.bh + dh; gw = r.bw + dw;
+        const int gt = r.bt + dt, gh = r.bh + dh, gw = r.bw + dw;
+        if ((unsigned)gt >= (unsigned)g.Gt || (unsigned)gh >= (unsigned)g.Gh || (unsigned)gw >= (unsigned)g.Gw)
+          return zero;
+        return *(const uint4*)(A + (r.base + lut_off[tap] + cch));
       } else {
         const int nt = r.bt - dt, nh = r.bh - dh, nw = r.bw - dw;
-        ok = (((nt & sft) | (nh & sfh) | (nw & sfw)) == 0) && nt >= 0 && nh >= 0 && nw >= 0;
-        gt = nt >> sft; gh = nh >> sfh; gw = nw >> sfw;
+        if (unit_stride) {
+          if ((unsigned)nt >= (unsigned)g.Gt || (unsigned)nh >= (unsigned)g.Gh || (unsigned)nw >= (unsigned)g.Gw)
+            return zero;
+          return *(const uint4*)(A + (r.base - lut_off[tap] + cch));
+        }
+        bool ok = (((nt & sft) | (nh & sfh) | (nw & sfw)) == 0) && nt >= 0 && nh >= 0 && nw >= 0;
+        const int gt = nt >> sft, gh = nh >> sfh, gw = nw >> sfw;
+        ok = ok && gt < g.Gt && gh < g.Gh && gw < g.Gw;
+        if (!ok) return zero;
+        return *(const uint4*)(A + ((r.nbase + (gt * g.Gh + gh) * g.Gw + gw) * g.cstride + cch));
       }
-      ok = ok && (unsigned)gt < (unsigned)g.Gt && (unsigned)gh < (unsigned)g.Gh &&
-           (unsigned)gw < (unsigned)g.Gw;
-      if (!ok) return zero;
-      const long long pos = r.base + ((long long)gt * g.Gh + gh) * g.Gw + gw;
-      return *(const uint4*)(A + pos * g.cstride + cch);
     }
   };
-  auto load_b = [&](int i) -> uint4 {
+  const bfraw* brow_ptr[NBI];
+#pragma unroll
+  for (int i = 0; i < NBI; ++i) {
     const int brow = (tid >> 2) + 64 * i;
     const int n = nb * BN + brow;
-    if (brow < BN && n < p.b_rows && kcur < p.K) return *(const uint4*)(Bt + (long long)n * p.ldb + kcur);
+    brow_ptr[i] = (brow < BN && n < p.b_rows) ? Bt + (long long)n * p.ldb : nullptr;
+  }
+  auto load_b = [&](int i) -> uint4 {
+    if (brow_ptr[i] != nullptr && kcur < p.K) return *(const uint4*)(brow_ptr[i] + kcur);
     return make_uint4(0, 0, 0, 0);
   };
   auto advance_k = [&]() {
@@ -157,46 +174,57 @@ __global__ __launch_bounds__(256) void igemm_kernel(const pp_igemm_desc p, const
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // ---- main loop: two register stages of global loads in flight (prefetch distance 2) and two LDS
+  // buffers, so each K-step costs one barrier and its loads had a full step (+ compute) to land.
   const int nk = (p.K + BK - 1) / BK;
-  uint4 ra[2], rb[NBI];
-  ra[0] = load_a(0);
-  ra[1] = load_a(1);
+  uint4 ra0[2], rb0[NBI], ra1[2], rb1[NBI];
+  auto load_stage = [&](uint4* ra, uint4* rb) {
+    ra[0] = load_a(0);
+    ra[1] = load_a(1);
 #pragma unroll
-  for (int i = 0; i < NBI; ++i) rb[i] = load_b(i);
-
-  const int fr = lane & 15, fq = lane >> 4;
-  const int fsw = (fq ^ swz(fr)) << 4;
-
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage registers -> LDS
+    for (int i = 0; i < NBI; ++i) rb[i] = load_b(i);
+    advance_k();
+  };
+  auto store_stage = [&](const uint4* ra, const uint4* rb, unsigned char* buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (tid >> 2) + 64 * i;
-      *(uint4*)(smem + row * 64 + ((kq ^ swz(row)) << 4)) = ra[i];
+      *(uint4*)(buf + row * 64 + ((kq ^ swz(row)) << 4)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
       const int row = (tid >> 2) + 64 * i;
-      if (row < BN) *(uint4*)(smem + A_BYTES + row * 64 + ((kq ^ swz(row)) << 4)) = rb[i];
+      if (row < BN) *(uint4*)(buf + A_BYTES + row * 64 + ((kq ^ swz(row)) << 4)) = rb[i];
     }
-    __syncthreads();
-    if (kt + 1 < nk) {  // next tile's global loads fly under this tile's MFMAs
-      advance_k();
-      ra[0] = load_a(0);
-      ra[1] = load_a(1);
-#pragma unroll
-      for (int i = 0; i < NBI; ++i) rb[i] = load_b(i);
-    }
+  };
+  const int fr = lane & 15, fq = lane >> 4;
+  const int fsw = (fq ^ swz(fr)) << 4;
+  auto compute = [&](const unsigned char* buf) {
     bf16x8 af[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-      af[mt] = *(const bf16x8*)(smem + (wave * 32 + mt * 16 + fr) * 64 + fsw);
+    for (int mt = 0; mt < 2; ++mt) af[mt] = *(const bf16x8*)(buf + (wave * 32 + mt * 16 + fr) * 64 + fsw);
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      const bf16x8 bfm = *(const bf16x8*)(smem + A_BYTES + (j * 16 + fr) * 64 + fsw);
+      const bf16x8 bfm = *(const bf16x8*)(buf + A_BYTES + (j * 16 + fr) * 64 + fsw);
       acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfm, acc[0][j], 0, 0, 0);
       acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfm, acc[1][j], 0, 0, 0);
     }
+  };
+  unsigned char* buf0 = smem;
+  unsigned char* buf1 = smem + LOOP_BYTES;
+  load_stage(ra0, rb0);
+  if (nk > 1) load_stage(ra1, rb1);
+  store_stage(ra0, rb0, buf0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) load_stage(ra0, rb0);
+    compute(buf0);
+    if (kt + 1 < nk) store_stage(ra1, rb1, buf1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) load_stage(ra1, rb1);
+    compute(buf1);
+    if (kt + 2 < nk) store_stage(ra0, rb0, buf0);
     __syncthreads();
   }
 
@@ -384,6 +412,12 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   if (d.g.mode != PP_DENSE) {
     const long long rows = (long long)d.g.Rt * d.g.Rh * d.g.Rw;
     PP_CHECK_ARG(d.M % rows == 0, "pp_igemm: M=%d is not a multiple of Rt*Rh*Rw=%lld", d.M, rows);
+  }
+  if (d.g.mode != PP_DENSE) {
+    const long long src = (long long)(d.M / ((long long)d.g.Rt * d.g.Rh * d.g.Rw)) * d.g.Gt * d.g.Gh * d.g.Gw * d.g.cstride;
+    PP_CHECK_ARG(src < 0x7fffffffLL, "pp_igemm: gathered tensor has %lld elements (>= 2^31)", src);
+  } else {
+    PP_CHECK_ARG((long long)d.M * d.g.lda < 0x7fffffffLL, "pp_igemm: dense operand >= 2^31 elements");
   }
   hipStream_t s = (hipStream_t)stream;
   const int n16 = (d.N + 15) / 16;

@@ -87,28 +87,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const pp_wgrad_desc p, const
     dt = e & 0xff; dh = (e >> 8) & 0xff; dw = (e >> 16) & 0xff;
   }
 
+  const int qt0 = dt - g.pt, qh0 = dh - g.ph, qw0 = dw - g.pw;
   auto load_q = [&](int m) -> uint4 {
     const uint4 zero = make_uint4(0, 0, 0, 0);
     if (!jq_ok || m >= m_end) return zero;
-    if (MODE == PP_DENSE) return *(const uint4*)(X + (long long)m * g.lda + jq);
+    if (MODE == PP_DENSE) return *(const uint4*)(X + (m * g.lda + jq));
     const uint32_t t1 = fdiv((uint32_t)m, wg.dRw);
     const int rw = m - t1 * g.Rw;
     const uint32_t t2 = fdiv(t1, wg.dRh);
     const int rh = t1 - t2 * g.Rh;
     const uint32_t n = fdiv(t2, wg.dRt);
     const int rt = t2 - n * g.Rt;
-    const int gt = rt * g.st - g.pt + dt, gh = rh * g.sh - g.ph + dh, gw = rw * g.sw - g.pw + dw;
+    const int gt = rt * g.st + qt0, gh = rh * g.sh + qh0, gw = rw * g.sw + qw0;
     if ((unsigned)gt >= (unsigned)g.Gt || (unsigned)gh >= (unsigned)g.Gh || (unsigned)gw >= (unsigned)g.Gw)
       return zero;
-    const long long pos = (((long long)n * g.Gt + gt) * g.Gh + gh) * g.Gw + gw;
-    return *(const uint4*)(X + pos * g.cstride + cch);
+    // 32-bit element offsets (host-checked: the source tensor has < 2^31 elements)
+    return *(const uint4*)(X + ((((int)n * g.Gt + gt) * g.Gh + gh) * g.Gw + gw) * g.cstride + cch);
   };
   auto load_p = [&](int it, int mbase) -> uint4 {
     const int cid = tid + 256 * it;
     const int row = cid / (2 * WI), ch = cid % (2 * WI);
     const int m = mbase + row;
     const int i = i0 + ch * 8;
-    if (row < MS && m < m_end && i < p.ldy) return *(const uint4*)(dY + (long long)m * p.ldy + i);
+    if (row < MS && m < m_end && i < p.ldy) return *(const uint4*)(dY + (m * p.ldy + i));
     return make_uint4(0, 0, 0, 0);
   };
 
@@ -213,10 +214,11 @@ int launch_wi(const pp_wgrad_desc& d, hipStream_t s) {
   int msplit = d.msplit;
   const long long steps = ((long long)d.M + MS - 1) / MS;
   if (msplit <= 0) {
-    // aim for ~2048 workgroups, at least 8 K-steps each
+    // aim for ~2048 workgroups with at least 24 steps each: every split adds one fp32 atomic per
+    // output element (chip-wide atomic rate ~1.3 TB/s), so short splits are atomics-bound
     const long long tiles = (long long)nblk_i * nblk_j * d.nbatch;
     long long want = (2048 + tiles - 1) / tiles;
-    const long long maxs = (steps + 7) / 8;
+    const long long maxs = (steps + 23) / 24;
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     msplit = (int)want;
@@ -252,6 +254,14 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
   if (d.nbatch <= 0) d.nbatch = 1;
   const int rc = pp_validate_gather(d.g, d.Kj, "pp_wgrad");
   if (rc != PP_OK) return rc;
+  PP_CHECK_ARG((long long)d.M * d.ldy < 0x7fffffffLL, "pp_wgrad: dY has >= 2^31 elements");
+  if (d.g.mode == PP_DENSE) {
+    PP_CHECK_ARG((long long)d.M * d.g.lda < 0x7fffffffLL, "pp_wgrad: X has >= 2^31 elements");
+  } else {
+    const long long rows = (long long)d.g.Rt * d.g.Rh * d.g.Rw;
+    PP_CHECK_ARG(d.M % rows == 0 && (d.M / rows) * d.g.Gt * d.g.Gh * d.g.Gw * d.g.cstride < 0x7fffffffLL,
+                 "pp_wgrad: gathered tensor >= 2^31 elements or M not a multiple of Rt*Rh*Rw");
+  }
   hipStream_t s = (hipStream_t)stream;
   switch (pick_wi((d.Ni + 15) / 16)) {
     case 15: return launch_wi<15>(d, s);
