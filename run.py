@@ -1,0 +1,66 @@
+"""Entry point with the reference's CLI (run.py:64-71): `python run.py --config_file hparams_base.yaml`.
+
+Differences forced by the offline environment (DESIGN.md "Out of scope"): the Peppa dataset,
+moviepy and the pretrained checkpoints are unavailable, so training runs on synthetic clips of the
+configured shape with random-init weights; with pytorch_lightning installed the same module is
+handed to `pl.Trainer`, otherwise to the minimal loop in peppa_amd.trainer.  Top-level config keys
+can be overridden from the command line exactly as in the reference (run.py:25-27)."""
+import logging
+import os
+from argparse import ArgumentParser
+
+import torch
+import yaml
+
+import pig.models
+from pig.execution import default_config
+from peppa_amd.trainer import SyntheticPigData, Trainer
+
+
+def get_git_commit():
+    try:  # GitPython is optional; never fail outside a git checkout
+        import git
+        return git.Repo(os.getcwd()).head.reference.commit.hexsha
+    except Exception:
+        return None
+
+
+def main(args):
+    logging.getLogger().setLevel(logging.INFO)
+    logging.basicConfig()
+    config = default_config if args.config_file is None else yaml.safe_load(open(args.config_file))
+    for key, value in vars(args).items():
+        if key in config and value is not None:
+            config[key] = value
+    config['git_commit'] = get_git_commit()
+    if args.random_init:
+        config['video']['pretrained'] = False
+        config['audio']['pretrained'] = False
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    data = SyntheticPigData(config['data'], frames=args.frames, size=args.size, samples=args.samples,
+                            steps_per_epoch=args.limit_train_batches or 100, device=f"cuda:{local_rank}")
+    net = pig.models.PeppaPig(config).to(f"cuda:{local_rank}")
+    targs = dict(config['training']['trainer_args'])
+    trainer = Trainer(accumulate_grad_batches=targs.get('accumulate_grad_batches', 1),
+                      limit_train_batches=args.limit_train_batches, max_time_s=2 * 24 * 3600)
+    trainer.fit(net, data)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    parser = ArgumentParser()
+    parser.add_argument("--config_file", help="Configuration file (YAML)", default=None)
+    parser.add_argument("--limit_train_batches", type=int, default=None)
+    parser.add_argument("--limit_val_batches", type=int, default=None)
+    parser.add_argument("--margin", type=float, default=None)
+    parser.add_argument("--random_init", action="store_true", default=True,
+                        help="weights cannot be downloaded offline; build the same architectures from random init")
+    parser.add_argument("--frames", type=int, default=16)
+    parser.add_argument("--size", type=int, default=112)
+    parser.add_argument("--samples", type=int, default=36800)
+    main(parser.parse_args())

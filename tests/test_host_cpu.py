@@ -1,0 +1,141 @@
+"""CPU-side checks (no GPU): the C ABI library loads and exports every symbol the header declares,
+host logic of the pig.* mirror, config files, and the no-fallback rule."""
+import copy
+import os
+import re
+import numpy as np
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from peppa_amd import _lib
+    header = open(os.path.join(ROOT, "include", "peppa_hip.h")).read()
+    declared = set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pp_status", "pp_act", "pp_gather_mode"}
+    assert len(declared) >= 45
+    h = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(h, name), f"{name} declared in include/peppa_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) <= declared, set(_lib.SIGNATURES) - declared
+    assert h.pp_version() >= 100
+    assert isinstance(h.pp_last_error(), bytes)
+
+
+def test_struct_layouts_match_header_order():
+    from peppa_amd import _lib
+    header = open(os.path.join(ROOT, "include", "peppa_hip.h")).read()
+    body = header[header.index("typedef struct pp_gather {"):header.index("} pp_gather;")]
+    names = re.findall(r"\b([A-Za-z_]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert [n for n in names if n != "int"] == [f[0] for f in _lib.Gather._fields_]
+
+
+def test_no_cpu_fallback():
+    import pig.models
+    import pig.loss
+    from peppa_amd._lib import PeppaHipError
+    with pytest.raises(PeppaHipError):
+        pig.loss.TripletLoss(0.2)(torch.randn(4, 8), torch.randn(4, 8))
+    from peppa_amd import audio
+    m = audio.wav2vec2_base(28)
+    with pytest.raises(PeppaHipError):
+        m(torch.zeros(1, 4000))
+    assert "oracle" not in " ".join(sorted(k for k in __import__("sys").modules if k.startswith("peppa_amd")))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "peppa_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+    for f in ("run.py", "pig/__init__.py"):
+        assert not re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(ROOT, f)).read(), flags=re.M)
+
+
+def test_state_dict_names_match_oracle_and_reference_layout():
+    import warnings
+    warnings.filterwarnings("ignore")
+    import pig.models
+    from pig.execution import default_config
+    from oracle import model as O
+    cfg = copy.deepcopy(default_config)
+    cfg["video"]["pretrained"] = False
+    cfg["audio"]["pretrained"] = False
+    net, ref = pig.models.PeppaPig(cfg), O.PeppaPigOracle(cfg)
+    a, b = net.state_dict(), ref.state_dict()
+    assert set(a) == set(b)
+    assert all(a[k].shape == b[k].shape for k in a)
+    assert "video_encoder.video.layer1.0.conv1.0.0.weight" in a
+    assert "audio_encoder.audio.encoder.transformer.layers.0.attention.k_proj.weight" in a
+    assert sum(p.numel() for p in net.parameters()) == 126314341
+    # freeze config: feature extractor + 12 layers frozen, the rest of the audio tower trains
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["audio"]["freeze_feature_extractor"] = True
+    cfg2["audio"]["freeze_encoder_layers"] = 12
+    n2 = pig.models.PeppaPig(cfg2)
+    trainable = sum(p.numel() for p in n2.audio_encoder.parameters() if p.requires_grad)
+    assert trainable == 5159736  # ~5.16 M
+    assert n2.audio_encoder.audio.encoder.transformer.pos_conv_embed.conv.weight_v.requires_grad
+
+
+def test_config_errors_and_yaml_files():
+    import pig.models
+    from pig.execution import default_config, conditions
+    for name, cond in conditions().items():
+        on_disk = yaml.safe_load(open(os.path.join(ROOT, f"hparams_{name}.yaml")))
+        if name == "static":
+            cond = copy.deepcopy(cond)
+            cond["video"]["pretrained"] = False   # as committed in the reference's hparams_static.yaml
+        assert on_disk == cond, name
+    bad = copy.deepcopy(default_config)
+    bad["video"]["pretrained"] = bad["audio"]["pretrained"] = False
+    bad["audio"]["pooling"] = "max"
+    with pytest.raises(ValueError, match="Invalid pooling"):
+        pig.models.PeppaPig(bad)
+    with pytest.raises(RuntimeError, match="fairseq"):
+        pig.models.PeppaPig(copy.deepcopy(default_config))
+
+
+def test_bertadam_host_side(golden_dir):
+    import pig.optimization as opt
+    d = np.load(os.path.join(golden_dir, "ref_bertadam.npz"))
+    for s, m in zip(d["sched_steps"], d["sched_mult"]):
+        assert abs(opt.warmup_linear(s / 15000, 0.1) - m) < 1e-12
+    assert opt.warmup_constant(0.5, 0.1) == 1.0 and abs(opt.warmup_cosine(0.05, 0.1) - 0.5) < 1e-12
+    p = torch.nn.Parameter(torch.zeros(3))
+    for kw in (dict(lr=-1.0), dict(lr=1e-3, schedule="nope"), dict(lr=1e-3, warmup=1.5), dict(lr=1e-3, b1=1.0),
+               dict(lr=1e-3, e=-1.0)):
+        with pytest.raises(ValueError):
+            opt.BertAdam([p], **kw)
+    o = opt.BertAdam([p], lr=1e-3, warmup=0.1, t_total=10)
+    assert o.get_lr() == [0]
+    p.grad = torch.ones(3)
+    from peppa_amd._lib import PeppaHipError
+    with pytest.raises(PeppaHipError):  # CPU parameters: no fallback
+        o.step()
+
+
+def test_triplet_pairing_and_geometry():
+    import random
+    import pig.triplet as T
+    from peppa_amd.layers import ConvGeom, cpad
+    from peppa_amd.audio import n_frames
+    assert T.pairs([1, 2, 3, 4, 5]) == [[1, 2], [3, 4]]
+    random.seed(0)
+    dur = [1, 1, 2, 2, 2, 3, 1, 1]
+    trip = list(T._triplets(range(len(dur)), lambda i: dur[i]))
+    assert len(trip) == 3 and all(dur[a] == dur[b] and a != b for a, b in trip)
+    assert [n_frames(n) for n in (16000, 36800, 73600, 101429)] == [49, 114, 229, 316]
+    g = ConvGeom(64, (16, 56, 56), 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    assert (g.M, g.Kf, g.Kd, g.out_cstride) == (64 * 16 * 56 * 56, 576, 9 * 144, 144)
+    g = ConvGeom(2, (8, 28, 28), 64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    assert g.out_thw == (8, 14, 14) and g.out_cstride == 240 and cpad(921) == 928
+    from peppa_amd.data import Clip, collate
+    b = collate([Clip(torch.zeros(3, 4, 8, 8), torch.zeros(1, 100)), Clip(torch.zeros(3, 6, 8, 8), torch.zeros(1, 80))])
+    assert b.video.shape == (2, 3, 6, 8, 8) and b.audio.shape == (2, 1, 100)
+    assert b.video_duration.tolist() == [4, 6] and b.audio_duration.tolist() == [100, 80]
