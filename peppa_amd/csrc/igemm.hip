@@ -17,32 +17,43 @@
 namespace {
 
 constexpr int BM = 128;
-constexpr int BK = 32;
+constexpr int BK = 64;
+constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond every buffer: the buffer load returns zeros
 
-__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-struct RowInfo {
-  int base;          // dense: row offset; conv: offset of (n, bt, bh, bw) in elements (may be "virtual")
-  int nbase;         // conv: n * Gt*Gh*Gw (positions)
-  int bt, bh, bw;
-  int valid;
+// 128-byte LDS rows (64 bf16): 16-byte chunk c of row r lives at chunk c ^ swz(r); with this XOR the
+// four 16-lane groups of a ds_read_b128 fragment read (rows 0-3/12-15 at chunk q, rows 4-11 at q+1) hit
+// 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+struct RowDiv {  // exact division by the row-decomposition extents (host-prepared magic numbers)
+  FastDiv dRw, dRh, dRt;
 };
 
-template <int WN, int MODE>
-__global__ __launch_bounds__(256, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_igemm_desc p, const int nblk_n) {
+struct RowInfo {
+  unsigned base;     // byte offset of the row origin in the source tensor (conv: may be "virtual")
+  int bt, bh, bw;    // conv: origin coordinates; invalid rows carry bt = -2^20 so every range check fails
+  int nbase;         // strided data-gradient only: n * Gt*Gh*Gw
+};
+
+template <int WN, int MODE, bool FULL>
+__global__ __launch_bounds__(256, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_igemm_desc p, const int nblk_n,
+                                                                       const RowDiv rd) {
   constexpr int BN = 16 * WN;
-  constexpr int A_BYTES = BM * 64;
-  constexpr int B_BYTES = BN * 64;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int B_BYTES = BN * 128;
   constexpr int STG_STRIDE = BN * 2 + 16;
   constexpr int STG_BYTES = 4 * 16 * STG_STRIDE;
   constexpr int STAT_BYTES = 4 * BN * 2 * 4;
   constexpr int LOOP_BYTES = A_BYTES + B_BYTES;
   constexpr int EPI_BYTES = STG_BYTES + STAT_BYTES;
   constexpr int SMEM = 2 * LOOP_BYTES > EPI_BYTES ? 2 * LOOP_BYTES : EPI_BYTES;
-  constexpr int NBI = (BN * 4 + 255) / 256;
+  constexpr int NAI = 4;                       // A chunks per thread and K-step
+  constexpr int NBI = (BN * 8 + 255) / 256;    // B chunks per thread and K-step
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   __shared__ int lut[128];      // packed (dt, dh, dw) per tap
-  __shared__ int lut_off[128];  // element offset of the tap inside the source tensor (linear part)
+  __shared__ int lut_off[128];  // byte offset of the tap inside the source tensor (linear part)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -52,51 +63,56 @@ __global__ __launch_bounds__(256, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_
   const int z = blockIdx.z;
   const int zo = z / p.inner, zi = z % p.inner;
 
-  const bfraw* __restrict__ A = (const bfraw*)p.A + zo * p.a_s0 + zi * p.a_s1;
-  const bfraw* __restrict__ Bt = (const bfraw*)p.Bt + zo * p.b_s0 + zi * p.b_s1;
+  const bfraw* A = (const bfraw*)p.A + zo * p.a_s0 + zi * p.a_s1;
+  const bfraw* Bt = (const bfraw*)p.Bt + zo * p.b_s0 + zi * p.b_s1;
   const long long c_off = zo * p.c_s0 + zi * p.c_s1;
   const float* __restrict__ bias = p.bias ? p.bias + zo * p.bias_s0 + zi * p.bias_s1 : nullptr;
+  // raw buffer descriptors (wave-uniform): an offset of OOB is out of range and loads zeros, which
+  // replaces every validity branch of the gather by one v_cndmask on the offset
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, (int)OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bt, (short)0, (int)OOB, 0x00020000);
 
   const pp_gather& g = p.g;
   const int ntaps = g.kt * g.kh * g.kw;
   if (MODE != PP_DENSE) {
     if (tid < 128) {
-      int e = 0;
+      int e = 0, o = 0;
       if (tid < ntaps) {
         const int dw = tid % g.kw;
         const int t2 = tid / g.kw;
         const int dh = t2 % g.kh;
         const int dt = t2 / g.kh;
         e = dt | (dh << 8) | (dw << 16);
-        lut_off[tid] = ((dt * g.Gh + dh) * g.Gw + dw) * g.cstride;
+        o = ((dt * g.Gh + dh) * g.Gw + dw) * g.cstride * 2;
       }
       lut[tid] = e;
+      lut_off[tid] = o;
     }
     __syncthreads();
   }
-  // stride-1 gathers are linear in the tap: offset = row_base +/- lut_off[tap] (32-bit element offsets;
-  // the host checks that the source tensor has < 2^31 elements)
+  // stride-1 gathers are linear in the tap: offset = row_base +/- lut_off[tap]
   const bool unit_stride = (g.st == 1 && g.sh == 1 && g.sw == 1);
+  const int sft = g.st == 2, sfh = g.sh == 2, sfw = g.sw == 2;
 
-  // ---- per-thread row bookkeeping (two A rows per thread) --------------------------------
-  const int kq = tid & 3;
-  RowInfo ri[2];
+  // ---- per-thread bookkeeping: 4 A rows (tid>>3 + 32 i) and NBI B rows, one 16-byte chunk column kq ----
+  const int kq = tid & 7;
+  RowInfo ri[NAI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = mb * BM + (tid >> 2) + 64 * i;
-    ri[i].valid = m < p.M;
-    const int mm = ri[i].valid ? m : 0;
+  for (int i = 0; i < NAI; ++i) {
+    const int m = mb * BM + (tid >> 3) + 32 * i;
+    const bool valid = m < p.M;
+    const int mm = valid ? m : 0;
+    ri[i].nbase = 0;
     if (MODE == PP_DENSE) {
-      ri[i].base = mm * g.lda;
-      ri[i].nbase = 0;
+      ri[i].base = valid ? (unsigned)(mm * g.lda) * 2u : OOB;
       ri[i].bt = ri[i].bh = ri[i].bw = 0;
     } else {
-      const int rw = mm % g.Rw;
-      int t = mm / g.Rw;
-      const int rh = t % g.Rh;
-      t /= g.Rh;
-      const int rt = t % g.Rt;
-      const int n = t / g.Rt;
+      const uint32_t t1 = fdiv((uint32_t)mm, rd.dRw);
+      const int rw = mm - (int)t1 * g.Rw;
+      const uint32_t t2 = fdiv(t1, rd.dRh);
+      const int rh = (int)t1 - (int)t2 * g.Rh;
+      const int n = (int)fdiv(t2, rd.dRt);
+      const int rt = (int)t2 - n * g.Rt;
       ri[i].nbase = n * g.Gt * g.Gh * g.Gw;
       if (MODE == PP_CONV_FWD) {
         ri[i].bt = rt * g.st - g.pt;
@@ -107,10 +123,17 @@ __global__ __launch_bounds__(256, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_
         ri[i].bh = rh + g.ph;
         ri[i].bw = rw + g.pw;
       }
-      ri[i].base = (ri[i].nbase + (ri[i].bt * g.Gh + ri[i].bh) * g.Gw + ri[i].bw) * g.cstride;
+      ri[i].base = (unsigned)((ri[i].nbase + (ri[i].bt * g.Gh + ri[i].bh) * g.Gw + ri[i].bw) * g.cstride) * 2u;
+      if (!valid) ri[i].bt = -(1 << 20);
     }
   }
-  const int sft = g.st == 2, sfh = g.sh == 2, sfw = g.sw == 2;
+  unsigned bbase[NBI];
+#pragma unroll
+  for (int i = 0; i < NBI; ++i) {
+    const int brow = (tid >> 3) + 32 * i;
+    const int n = nb * BN + brow;
+    bbase[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : OOB;
+  }
 
   int kcur = kq * 8;            // this thread's k within the current K-step
   int tap = 0, cch = 0;         // conv modes: k = tap*cg + cch
@@ -119,52 +142,65 @@ __global__ __launch_bounds__(256, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_
     cch = kcur % g.cg;
   }
 
-  auto load_a = [&](int i) -> uint4 {
-    const RowInfo& r = ri[i];
-    const uint4 zero = make_uint4(0, 0, 0, 0);
+  u32x4 ra[NAI], rb[NBI];
+  auto load_stage = [&]() __attribute__((always_inline)) {
+    const bool k_ok = kcur < p.K;
     if (MODE == PP_DENSE) {
-      if (r.valid && kcur < p.K) return *(const uint4*)(A + (r.base + kcur));
-      return zero;
+#pragma unroll
+      for (int i = 0; i < NAI; ++i) {
+        const unsigned off = (k_ok && ri[i].base != OOB) ? ri[i].base + (unsigned)kcur * 2u : OOB;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+      }
     } else {
-      if (!r.valid || tap >= ntaps) return zero;
-      const int e = lut[tap];
+      const bool tap_ok = tap < ntaps;
+      const int e = lut[tap & 127];
+      const int toff = lut_off[tap & 127] + cch * 2;
       const int dt = e & 0xff, dh = (e >> 8) & 0xff, dw = (e >> 16) & 0xff;
-      if (MODE == PP_CONV_FWD) {
-        const int gt = r.bt + dt, gh = r.bh + dh, gw = r.bw + dw;
-        if ((unsigned)gt >= (unsigned)g.Gt || (unsigned)gh >= (unsigned)g.Gh || (unsigned)gw >= (unsigned)g.Gw)
-          return zero;
-        return *(const uint4*)(A + (r.base + lut_off[tap] + cch));
-      } else {
-        const int nt = r.bt - dt, nh = r.bh - dh, nw = r.bw - dw;
-        if (unit_stride) {
-          if ((unsigned)nt >= (unsigned)g.Gt || (unsigned)nh >= (unsigned)g.Gh || (unsigned)nw >= (unsigned)g.Gw)
-            return zero;
-          return *(const uint4*)(A + (r.base - lut_off[tap] + cch));
+#pragma unroll
+      for (int i = 0; i < NAI; ++i) {
+        const RowInfo& r = ri[i];
+        unsigned off;
+        bool ok;
+        if (MODE == PP_CONV_FWD) {
+          const int gt = r.bt + dt, gh = r.bh + dh, gw = r.bw + dw;
+          ok = tap_ok && (unsigned)gt < (unsigned)g.Gt && (unsigned)gh < (unsigned)g.Gh && (unsigned)gw < (unsigned)g.Gw;
+          off = r.base + (unsigned)toff;
+        } else {
+          const int nt = r.bt - dt, nh = r.bh - dh, nw = r.bw - dw;
+          if (unit_stride) {
+            ok = tap_ok && (unsigned)nt < (unsigned)g.Gt && (unsigned)nh < (unsigned)g.Gh && (unsigned)nw < (unsigned)g.Gw;
+            off = r.base - (unsigned)lut_off[tap & 127] + (unsigned)cch * 2u;
+          } else {
+            const int gt = nt >> sft, gh = nh >> sfh, gw = nw >> sfw;
+            ok = tap_ok && (((nt & sft) | (nh & sfh) | (nw & sfw)) == 0) && nt >= 0 && nh >= 0 && nw >= 0 &&
+                 gt < g.Gt && gh < g.Gh && gw < g.Gw;
+            off = (unsigned)((r.nbase + (gt * g.Gh + gh) * g.Gw + gw) * g.cstride + cch) * 2u;
+          }
         }
-        bool ok = (((nt & sft) | (nh & sfh) | (nw & sfw)) == 0) && nt >= 0 && nh >= 0 && nw >= 0;
-        const int gt = nt >> sft, gh = nh >> sfh, gw = nw >> sfw;
-        ok = ok && gt < g.Gt && gh < g.Gh && gw < g.Gw;
-        if (!ok) return zero;
-        return *(const uint4*)(A + ((r.nbase + (gt * g.Gh + gh) * g.Gw + gw) * g.cstride + cch));
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : OOB, 0, 0);
       }
     }
-  };
-  const bfraw* brow_ptr[NBI];
 #pragma unroll
-  for (int i = 0; i < NBI; ++i) {
-    const int brow = (tid >> 2) + 64 * i;
-    const int n = nb * BN + brow;
-    brow_ptr[i] = (brow < BN && n < p.b_rows) ? Bt + (long long)n * p.ldb : nullptr;
-  }
-  auto load_b = [&](int i) -> uint4 {
-    if (brow_ptr[i] != nullptr && kcur < p.K) return *(const uint4*)(brow_ptr[i] + kcur);
-    return make_uint4(0, 0, 0, 0);
-  };
-  auto advance_k = [&]() {
+    for (int i = 0; i < NBI; ++i) {
+      const unsigned off = (k_ok && bbase[i] != OOB) ? bbase[i] + (unsigned)kcur * 2u : OOB;
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
+    }
     kcur += BK;
     if (MODE != PP_DENSE) {
       cch += BK;
       while (cch >= g.cg) { cch -= g.cg; ++tap; }
+    }
+  };
+  auto store_stage = [&](unsigned char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      *(u32x4*)(buf + row * 128 + ((kq ^ swz(row)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      if (row < BN) *(u32x4*)(buf + A_BYTES + row * 128 + ((kq ^ swz(row)) << 4)) = rb[i];
     }
   };
 
@@ -174,148 +210,160 @@ __global__ __launch_bounds__(256, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- main loop: two register stages of global loads in flight (prefetch distance 2) and two LDS
-  // buffers, so each K-step costs one barrier and its loads had a full step (+ compute) to land.
-  const int nk = (p.K + BK - 1) / BK;
-  uint4 ra0[2], rb0[NBI], ra1[2], rb1[NBI];
-  auto load_stage = [&](uint4* ra, uint4* rb) {
-    ra[0] = load_a(0);
-    ra[1] = load_a(1);
-#pragma unroll
-    for (int i = 0; i < NBI; ++i) rb[i] = load_b(i);
-    advance_k();
-  };
-  auto store_stage = [&](const uint4* ra, const uint4* rb, unsigned char* buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = (tid >> 2) + 64 * i;
-      *(uint4*)(buf + row * 64 + ((kq ^ swz(row)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NBI; ++i) {
-      const int row = (tid >> 2) + 64 * i;
-      if (row < BN) *(uint4*)(buf + A_BYTES + row * 64 + ((kq ^ swz(row)) << 4)) = rb[i];
-    }
-  };
   const int fr = lane & 15, fq = lane >> 4;
-  const int fsw = (fq ^ swz(fr)) << 4;
-  auto compute = [&](const unsigned char* buf) {
-    bf16x8 af[2];
+  auto compute = [&](const unsigned char* buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) af[mt] = *(const bf16x8*)(buf + (wave * 32 + mt * 16 + fr) * 64 + fsw);
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fsw = ((ks * 4 + fq) ^ swz(fr)) << 4;
+      bf16x8 af[2];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const bf16x8 bfm = *(const bf16x8*)(buf + A_BYTES + (j * 16 + fr) * 64 + fsw);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfm, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfm, acc[1][j], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt) af[mt] = *(const bf16x8*)(buf + (wave * 32 + mt * 16 + fr) * 128 + fsw);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const bf16x8 bfm = *(const bf16x8*)(buf + A_BYTES + (j * 16 + fr) * 128 + fsw);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfm, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfm, acc[1][j], 0, 0, 0);
+      }
     }
   };
+
+  // ---- main loop: the next K-step's global loads (one register stage) fly under this step's MFMAs;
+  // two LDS buffers, one barrier per 64-deep K-step
+  const int nk = (p.K + BK - 1) / BK;
   unsigned char* buf0 = smem;
   unsigned char* buf1 = smem + LOOP_BYTES;
-  load_stage(ra0, rb0);
-  if (nk > 1) load_stage(ra1, rb1);
-  store_stage(ra0, rb0, buf0);
+  load_stage();
+  store_stage(buf0);
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) load_stage(ra0, rb0);
+    if (kt + 1 < nk) load_stage();
     compute(buf0);
-    if (kt + 1 < nk) store_stage(ra1, rb1, buf1);
+    if (kt + 1 < nk) store_stage(buf1);
     __syncthreads();
     if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) load_stage(ra1, rb1);
+    if (kt + 2 < nk) load_stage();
     compute(buf1);
-    if (kt + 2 < nk) store_stage(ra0, rb0, buf0);
+    if (kt + 2 < nk) store_stage(buf0);
     __syncthreads();
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
+  // FULL = bias / activation / residual / pre-activation copy; otherwise plain store (+ optional
+  // BatchNorm column statistics).  Flags are tested once, outside the per-value loops.
   const int m_wave = mb * BM + wave * 32;
+  if (FULL && bias) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = nb * BN + j * 16 + fr;
+      const float bv = n < p.N ? bias[n] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mt][j][r] += bv;
+    }
+  }
+  auto activate = [&]() __attribute__((always_inline)) {
+    if (p.act == PP_ACT_GELU) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][j][r] = gelu_f(acc[mt][j][r]);
+    } else if (p.act == PP_ACT_RELU) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][j][r] = fmaxf(acc[mt][j][r], 0.f);
+    }
+  };
   if (p.c_fp32) {
+    if (FULL) activate();
     float* C = (float*)p.C + c_off;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int n = nb * BN + j * 16 + fr;
-        const float bv = (bias && n < p.N) ? bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m_wave + mt * 16 + fq * 4 + r;
-          float v = acc[mt][j][r] + bv;
-          if (p.act == PP_ACT_GELU) v = gelu_f(v);
-          else if (p.act == PP_ACT_RELU) v = fmaxf(v, 0.f);
-          if (m < p.M && n < p.N) C[(long long)m * p.ldc + n] = v;
+          if (m < p.M && n < p.N) C[(long long)m * p.ldc + n] = acc[mt][j][r];
         }
       }
     return;
   }
 
+  // Each wave stages its own 16 x BN slab (bf16) in LDS and writes it out as full 16-byte row segments.
+  // The slab is wave-private, so LDS program order (+ lgkmcnt waits) is the only synchronisation needed.
   unsigned char* stg = smem + wave * 16 * STG_STRIDE;
-  float* statbuf = (float*)(smem + STG_BYTES);
+  unsigned char* stg_w = stg + (fq * 4) * STG_STRIDE + fr * 2;
   const int ncols_store = (p.N + 7) & ~7;
-  float s1[WN], s2[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j) s1[j] = s2[j] = 0.f;
-  const int npass = p.Cpre ? 2 : 1;
-  for (int pass = 0; pass < npass; ++pass) {
-    const bool pre_pass = (npass == 2 && pass == 0);
-    bfraw* Cout = (bfraw*)(pre_pass ? p.Cpre : p.C) + c_off;
+  auto write_out = [&](bfraw* Cout, const bfraw* residual) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int col = j * 16 + fr;
-        const int n = nb * BN + col;
-        const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+      for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[mt][j][r] + bv;
-          if (!pre_pass) {
-            if (p.act == PP_ACT_GELU) v = gelu_f(v);
-            else if (p.act == PP_ACT_RELU) v = fmaxf(v, 0.f);
-          }
-          const bfraw b = f2bf(v);
-          *(bfraw*)(stg + (fq * 4 + r) * STG_STRIDE + col * 2) = b;
-          if (p.colstats && !pre_pass) {
-            const float fb = bf2f(b);
-            s1[j] += fb;
-            s2[j] += fb * fb;
-          }
-        }
-      }
-      __syncthreads();
-      for (int cid = lane; cid < 32 * WN; cid += 64) {
+        for (int r = 0; r < 4; ++r) *(bfraw*)(stg_w + r * STG_STRIDE + j * 32) = f2bf(acc[mt][j][r]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < (32 * WN + 63) / 64; ++it) {
+        const int cid = lane + 64 * it;
         const int row = cid / (2 * WN);
         const int ch = cid % (2 * WN);
         const int m = m_wave + mt * 16 + row;
         const int col = nb * BN + ch * 8;
-        if (m < p.M && col < ncols_store) {
+        if (cid < 32 * WN && m < p.M && col < ncols_store) {
           uint4 v = *(const uint4*)(stg + row * STG_STRIDE + ch * 16);
-          if (p.residual && !pre_pass) {
-            const uint4 rv = *(const uint4*)((const bfraw*)p.residual + c_off + (long long)m * p.ldr + col);
-            float a[8], b[8];
-            unpack8(v, a);
-            unpack8(rv, b);
+          if (FULL && residual) {
+            const uint4 rv = *(const uint4*)(residual + c_off + (long long)m * p.ldr + col);
+            float x[8], y[8];
+            unpack8(v, x);
+            unpack8(rv, y);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] += b[q];
-            v = pack8(a);
+            for (int q = 0; q < 8; ++q) x[q] += y[q];
+            v = pack8(x);
           }
-          *(uint4*)(Cout + (long long)m * p.ldc + col) = v;
+          *(uint4*)(Cout + c_off + (long long)m * p.ldc + col) = v;
         }
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
+  };
+  if (FULL) {
+    if (p.Cpre) write_out((bfraw*)p.Cpre, nullptr);
+    activate();
+    write_out((bfraw*)p.C, (const bfraw*)p.residual);
+    return;
   }
+  write_out((bfraw*)p.C, nullptr);
   if (p.colstats) {
+    // per-column sum / sum of squares over this block's 128 rows (fp32 accumulators), deterministic:
+    // in-lane over 8 rows, xor-shuffles over the 4 row groups, LDS over the 4 waves
+    float* statbuf = (float*)(smem + STG_BYTES);
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      s1[j] += __shfl_xor(s1[j], 16);
-      s1[j] += __shfl_xor(s1[j], 32);
-      s2[j] += __shfl_xor(s2[j], 16);
-      s2[j] += __shfl_xor(s2[j], 32);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[mt][j][r];
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
       if (fq == 0) {
-        statbuf[(wave * BN + j * 16 + fr) * 2 + 0] = s1[j];
-        statbuf[(wave * BN + j * 16 + fr) * 2 + 1] = s2[j];
+        statbuf[(wave * BN + j * 16 + fr) * 2 + 0] = s1;
+        statbuf[(wave * BN + j * 16 + fr) * 2 + 1] = s2;
       }
     }
     __syncthreads();
@@ -356,10 +404,19 @@ int launch_wn(const pp_igemm_desc& d, hipStream_t s) {
   const long long gx = nblk_m * nblk_n;
   if (gx <= 0 || gx > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(256);
+  RowDiv rd;
+  const bool dense = d.g.mode == PP_DENSE;
+  rd.dRw = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rw));
+  rd.dRh = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rh));
+  rd.dRt = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rt));
+  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
+#define PP_LAUNCH_IGEMM(MODE_)                                                                                       \
+  if (full) hipLaunchKernelGGL((igemm_kernel<WN, MODE_, true>), grid, block, 0, s, d, nblk_n, rd);                   \
+  else hipLaunchKernelGGL((igemm_kernel<WN, MODE_, false>), grid, block, 0, s, d, nblk_n, rd)
   switch (d.g.mode) {
-    case PP_DENSE: hipLaunchKernelGGL((igemm_kernel<WN, PP_DENSE>), grid, block, 0, s, d, nblk_n); break;
-    case PP_CONV_FWD: hipLaunchKernelGGL((igemm_kernel<WN, PP_CONV_FWD>), grid, block, 0, s, d, nblk_n); break;
-    case PP_CONV_DGRAD: hipLaunchKernelGGL((igemm_kernel<WN, PP_CONV_DGRAD>), grid, block, 0, s, d, nblk_n); break;
+    case PP_DENSE: PP_LAUNCH_IGEMM(PP_DENSE); break;
+    case PP_CONV_FWD: PP_LAUNCH_IGEMM(PP_CONV_FWD); break;
+    case PP_CONV_DGRAD: PP_LAUNCH_IGEMM(PP_CONV_DGRAD); break;
     default: pp_set_error("pp_igemm: bad gather mode %d", d.g.mode); return PP_ERR_INVALID;
   }
   PP_LAUNCH_CHECK();
@@ -405,7 +462,8 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   } else {
     PP_CHECK_ARG(!d.residual && !d.Cpre && !d.colstats, "pp_igemm: fp32 output supports bias/act only");
   }
-  if (d.colstats) PP_CHECK_ARG(!d.bias && d.nbatch == 1 && d.ldstat >= d.N, "pp_igemm: colstats needs no bias, nbatch 1");
+  if (d.colstats) PP_CHECK_ARG(!d.bias && d.act == PP_ACT_NONE && !d.residual && !d.Cpre && d.nbatch == 1 && d.ldstat >= d.N,
+                               "pp_igemm: colstats needs a plain epilogue (no bias/act/residual/pre) and nbatch 1");
   PP_CHECK_ARG(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.Bt & 15) == 0, "pp_igemm: operands must be 16-byte aligned");
   const int rc = pp_validate_gather(d.g, d.K, "pp_igemm");
   if (rc != PP_OK) return rc;
@@ -415,10 +473,11 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   }
   if (d.g.mode != PP_DENSE) {
     const long long src = (long long)(d.M / ((long long)d.g.Rt * d.g.Rh * d.g.Rw)) * d.g.Gt * d.g.Gh * d.g.Gw * d.g.cstride;
-    PP_CHECK_ARG(src < 0x7fffffffLL, "pp_igemm: gathered tensor has %lld elements (>= 2^31)", src);
+    PP_CHECK_ARG(src < 0x7ffffff0LL, "pp_igemm: gathered tensor has %lld elements (>= 2^31)", src);
   } else {
     PP_CHECK_ARG((long long)d.M * d.g.lda < 0x7fffffffLL, "pp_igemm: dense operand >= 2^31 elements");
   }
+  PP_CHECK_ARG((long long)d.b_rows * d.ldb < 0x7ffffff0LL, "pp_igemm: Bt has >= 2^31 elements");
   hipStream_t s = (hipStream_t)stream;
   const int n16 = (d.N + 15) / 16;
   switch (pick_wn(n16)) {
