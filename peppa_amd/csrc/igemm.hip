@@ -230,20 +230,16 @@ __global__ __launch_bounds__(256, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_
   // ---- main loop: the next K-step's global loads (one register stage) fly under this step's MFMAs;
   // two LDS buffers, one barrier per 64-deep K-step
   const int nk = (p.K + BK - 1) / BK;
-  unsigned char* buf0 = smem;
-  unsigned char* buf1 = smem + LOOP_BYTES;
   load_stage();
-  store_stage(buf0);
+  store_stage(smem);
   __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 1 < nk) load_stage();
-    compute(buf0);
-    if (kt + 1 < nk) store_stage(buf1);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    if (kt + 2 < nk) load_stage();
-    compute(buf1);
-    if (kt + 2 < nk) store_stage(buf0);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {   // single loop body + runtime buffer toggle: half the registers of a 2x unroll
+    const bool more = kt + 1 < nk;
+    if (more) load_stage();
+    compute(smem + cur * LOOP_BYTES);
+    cur ^= 1;
+    if (more) store_stage(smem + cur * LOOP_BYTES);
     __syncthreads();
   }
 
