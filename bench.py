@@ -48,6 +48,10 @@ def parse():
 def cpu_baseline(cfg, args):
     """The CPU oracle (fp32, torch CPU threads) on a bounded sample of the same workload."""
     from oracle import model as O
+    try:  # threads actually available to this process (cgroup / affinity), not the host's core count
+        torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    except Exception:
+        pass
     torch.manual_seed(0)
     net = O.PeppaPigOracle(cfg, dropout=0.0, layer_drop=0.0).train()
     v, a = O.synthetic_batch(args.cpu_batch, args.frames, args.size, args.samples)
@@ -106,6 +110,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     H.PROFILE.clear()
+    H.PROFILE_STREAM = torch.cuda.current_stream()   # the video trunk's stream; the audio tower overlaps on a side stream
     H.PROFILE_ON = True
     torch.cuda.synchronize()
     if world > 1:

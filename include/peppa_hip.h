@@ -127,14 +127,17 @@ int pp_colstats_bf16(const void* y, long long M, int Cp, float* partials, int nb
 int pp_bn_apply(const void* y, const float* scale, const float* shift, const void* res, int relu, void* z,
                 long long M, int Cp, pp_stream_t s);
 /* backward: pass 1 partial sums of dzm and dzm*xhat (dzm = dz masked by z>0 when relu) */
+/* z may be NULL when there was no residual: the ReLU mask is then recomputed as y*scale+shift > 0 */
 int pp_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
-                     int relu, float* partials, int nblk, long long M, int Cp, pp_stream_t s);
+                     const float* scale, const float* shift, int relu, float* partials, int nblk, long long M,
+                     int Cp, pp_stream_t s);
 /* pass 2: sums -> dgamma,dbeta (C real channels), coefficient vectors for the apply pass */
 int pp_bn_bwd_finalize(const float* partials, int nblk, long long count, int C, int Cp, const float* gamma,
                        const float* rstd, float* dgamma, float* dbeta, float* coef, pp_stream_t s);
 /* pass 3: dy = gamma*rstd*(dzm - mean(dzm) - xhat*mean(dzm*xhat)); optional dres = dzm */
 int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
-                    const float* coef, int relu, void* dy, void* dres, long long M, int Cp, pp_stream_t s);
+                    const float* coef, const float* scale, const float* shift, int relu, void* dy, void* dres,
+                    long long M, int Cp, pp_stream_t s);
 
 /* ---- elementwise on bf16 [n] ------------------------------------------------------------ */
 int pp_gelu_fwd(const void* x, void* y, long long n, pp_stream_t s);

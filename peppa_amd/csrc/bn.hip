@@ -139,14 +139,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bfraw* __restrict__
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bfraw* __restrict__ dz, const bfraw* __restrict__ y,
                                                             const bfraw* __restrict__ z, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, int relu, long long M, int Cp,
+                                                            const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu, long long M, int Cp,
                                                             int rows_per_blk, float* partials) {
   col_reduce<2>(M, Cp, rows_per_blk, partials, [&](long long r, int ch, float (*acc)[8]) {
     const long long o = r * Cp + ch * 8;
     float d[8], yy[8], zz[8];
     unpack8(*(const uint4*)(dz + o), d);
     unpack8(*(const uint4*)(y + o), yy);
-    if (relu) unpack8(*(const uint4*)(z + o), zz);
+    if (relu) {
+      if (z) unpack8(*(const uint4*)(z + o), zz);
+      else  // no residual: the ReLU mask is recomputed from y instead of reading z (one stream less)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) zz[q] = yy[q] * scale[ch * 8 + q] + shift[ch * 8 + q];
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int c = ch * 8 + q;
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bfraw* __restrict__ dz, const bfraw* __restrict__ y,
                                                            const bfraw* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ coef,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int relu, bfraw* __restrict__ dy, bfraw* __restrict__ dres,
                                                            long long nchunks, int cpr, int Cp) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
@@ -197,7 +204,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bfraw* __restri
     float d[8], yy[8], zz[8], o[8];
     unpack8(*(const uint4*)(dz + i * 8), d);
     unpack8(*(const uint4*)(y + i * 8), yy);
-    if (relu) unpack8(*(const uint4*)(z + i * 8), zz);
+    if (relu) {
+      if (z) unpack8(*(const uint4*)(z + i * 8), zz);
+      else
+#pragma unroll
+        for (int q = 0; q < 8; ++q) zz[q] = yy[q] * scale[c0 + q] + shift[c0 + q];
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int c = c0 + q;
@@ -276,13 +288,14 @@ extern "C" int pp_bn_apply(const void* y, const float* scale, const float* shift
 }
 
 extern "C" int pp_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
-                                int relu, float* partials, int nblk, long long M, int Cp, pp_stream_t s) {
+                                const float* scale, const float* shift, int relu, float* partials, int nblk, long long M,
+                                int Cp, pp_stream_t s) {
   CHECK_CP(Cp, "pp_bn_bwd_reduce");
-  PP_CHECK_ARG(!relu || z, "pp_bn_bwd_reduce: relu needs z");
+  PP_CHECK_ARG(!relu || z || (scale && shift), "pp_bn_bwd_reduce: relu needs z or scale/shift");
   const int rows_per_blk = (int)((M + nblk - 1) / nblk);
   const int rpb = 256 / (Cp / 8);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), (size_t)rpb * 2 * Cp * 4, (hipStream_t)s,
-                     (const bfraw*)dz, (const bfraw*)y, (const bfraw*)z, mean, rstd, relu, M, Cp, rows_per_blk, partials);
+                     (const bfraw*)dz, (const bfraw*)y, (const bfraw*)z, mean, rstd, scale, shift, relu, M, Cp, rows_per_blk, partials);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -296,11 +309,13 @@ extern "C" int pp_bn_bwd_finalize(const float* partials, int nblk, long long cou
 }
 
 extern "C" int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
-                               const float* coef, int relu, void* dy, void* dres, long long M, int Cp, pp_stream_t s) {
+                               const float* coef, const float* scale, const float* shift, int relu, void* dy, void* dres,
+                               long long M, int Cp, pp_stream_t s) {
+  PP_CHECK_ARG(!relu || z || (scale && shift), "pp_bn_bwd_apply: relu needs z or scale/shift");
   CHECK_CP(Cp, "pp_bn_bwd_apply");
   const long long nchunks = M * (Cp / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nchunks)), dim3(256), 0, (hipStream_t)s, (const bfraw*)dz,
-                     (const bfraw*)y, (const bfraw*)z, mean, rstd, coef, relu, (bfraw*)dy, (bfraw*)dres, nchunks, Cp / 8, Cp);
+                     (const bfraw*)y, (const bfraw*)z, mean, rstd, coef, scale, shift, relu, (bfraw*)dy, (bfraw*)dres, nchunks, Cp / 8, Cp);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -58,8 +58,13 @@ PROFILE_MIN_FLOP = 2.0e10
 _MODE_NAMES = {DENSE: "dense", CONV_FWD: "conv_fwd", CONV_DGRAD: "conv_dgrad"}
 
 
+PROFILE_STREAM = None  # only launches on this stream are timed (the video trunk's stream in bench.py)
+
+
 def _profiled(key, flops, fn):
     if not PROFILE_ON or flops < PROFILE_MIN_FLOP:
+        return fn()
+    if PROFILE_STREAM is not None and torch.cuda.current_stream() != PROFILE_STREAM:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -174,9 +179,9 @@ def bn_apply(y, scale, shift, res, relu, z, M, Cp):
     call("pp_bn_apply", _p(y, bf16), _p(scale, f32), _p(shift, f32), _p(res, bf16), int(relu), _p(z, bf16), M, Cp, _s())
 
 
-def bn_bwd_reduce(dz, y, z, mean, rstd, relu, partials, nblk, M, Cp):
-    call("pp_bn_bwd_reduce", _p(dz, bf16), _p(y, bf16), _p(z, bf16), _p(mean, f32), _p(rstd, f32), int(relu),
-         _p(partials, f32), nblk, M, Cp, _s())
+def bn_bwd_reduce(dz, y, z, mean, rstd, scale, shift, relu, partials, nblk, M, Cp):
+    call("pp_bn_bwd_reduce", _p(dz, bf16), _p(y, bf16), _p(z, bf16), _p(mean, f32), _p(rstd, f32), _p(scale, f32),
+         _p(shift, f32), int(relu), _p(partials, f32), nblk, M, Cp, _s())
 
 
 def bn_bwd_finalize(partials, nblk, count, Cn, Cp, gamma, rstd, dgamma, dbeta, coef):
@@ -184,9 +189,9 @@ def bn_bwd_finalize(partials, nblk, count, Cn, Cp, gamma, rstd, dgamma, dbeta, c
          _p(dgamma, f32), _p(dbeta, f32), _p(coef, f32), _s())
 
 
-def bn_bwd_apply(dz, y, z, mean, rstd, coef, relu, dy, dres, M, Cp):
+def bn_bwd_apply(dz, y, z, mean, rstd, coef, scale, shift, relu, dy, dres, M, Cp):
     call("pp_bn_bwd_apply", _p(dz, bf16), _p(y, bf16), _p(z, bf16), _p(mean, f32), _p(rstd, f32), _p(coef, f32),
-         int(relu), _p(dy, bf16), _p(dres, bf16), M, Cp, _s())
+         _p(scale, f32), _p(shift, f32), int(relu), _p(dy, bf16), _p(dres, bf16), M, Cp, _s())
 
 
 # ---- elementwise ----------------------------------------------------------------------------------

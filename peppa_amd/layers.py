@@ -151,17 +151,18 @@ def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momen
 
 
 def bn_bwd(dz, y, z, sv, gamma, *, relu, want_dres=False):
-    """returns dy, dres (masked dz, for the skip connection), dgamma, dbeta."""
+    """returns dy, dres (masked dz, for the skip connection), dgamma, dbeta.
+    z=None (units without a residual input): the ReLU mask is recomputed from y, saving one stream."""
     M, Cp = y.shape
     nblk = min(2048, (M + 63) // 64)
     partials = empty((nblk, 2, Cp), f32, y)
-    H.bn_bwd_reduce(dz, y, z, sv.mean, sv.rstd, relu, partials, nblk, M, Cp)
+    H.bn_bwd_reduce(dz, y, z, sv.mean, sv.rstd, sv.scale, sv.shift, relu, partials, nblk, M, Cp)
     dgamma, dbeta = empty((sv.C,), f32, y), empty((sv.C,), f32, y)
     coef = empty((3, Cp), f32, y)
     H.bn_bwd_finalize(partials, nblk, sv.count, sv.C, Cp, gamma, sv.rstd, dgamma, dbeta, coef)
     dy = empty(y.shape, bf16, y)
     dres = empty(y.shape, bf16, y) if want_dres else None
-    H.bn_bwd_apply(dz, y, z, sv.mean, sv.rstd, coef, relu, dy, dres, M, Cp)
+    H.bn_bwd_apply(dz, y, z, sv.mean, sv.rstd, coef, sv.scale, sv.shift, relu, dy, dres, M, Cp)
     return dy, dres, dgamma, dbeta
 
 

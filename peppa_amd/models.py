@@ -249,6 +249,9 @@ class PeppaPig(_Base):
             self.video_encoder = R3DEncoder(**video_config)
         self.audio_encoder = Wav2VecEncoder(**config['audio'])
         self._logged = {}
+        # optional `mi355x:` block (ignored by the reference): run the two encoders on separate HIP streams
+        self._overlap = bool(config.get('mi355x', {}).get('overlap_encoders', True))
+        self._side_stream = None
 
     if pl is None:
         def log(self, name, value, **kwargs):
@@ -271,9 +274,26 @@ class PeppaPig(_Base):
     def encode_audio(self, x):
         return self.audio_encoder(x)
 
+    def encode_pair(self, video, audio):
+        """Both encoders; they are independent until the loss, so the audio tower (many small
+        kernels) runs on a side stream under the video trunk's large ones.  Autograd replays each
+        backward on its forward stream, so the overlap also holds for the backward pass."""
+        if not (self._overlap and video.is_cuda):
+            return self.encode_video(video), self.encode_audio(audio)
+        main = torch.cuda.current_stream()
+        if self._side_stream is None or self._side_stream.device != video.device:
+            self._side_stream = torch.cuda.Stream(device=video.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            A_ = self.encode_audio(audio)
+        V_ = self.encode_video(video)
+        main.wait_stream(side)
+        A_.record_stream(main)
+        return V_, A_
+
     def training_step(self, batch, batch_idx):
-        V_ = self.encode_video(batch.video)
-        A_ = self.encode_audio(batch.audio)
+        V_, A_ = self.encode_pair(batch.video, batch.audio)
         V_, A_ = gather_embeddings(V_, A_)  # data-parallel: global negative pool (identity on one GPU)
         loss = self.loss(V_, A_)
         # the reference logs loss.item() (a host sync per step, pig/models.py:264); log the tensor instead

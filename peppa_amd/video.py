@@ -164,6 +164,7 @@ def run_plan(plan, cur, thw, B, training, save, first=False):
             rec = _Tape()
             rec.conv, rec.bn, rec.relu, rec.geom, rec.wd = conv, bn, relu, geom, wd
             rec.x, rec.y, rec.z, rec.sv, rec.first = inp, y, z, sv, first
+            rec.has_res = residual is not None
         return z, geom.out_thw, rec
 
     for item in plan:
@@ -190,7 +191,9 @@ def trunk_backward(tape, dz, grads):
     """dz bf16 grad of the trunk output; fills `grads[param] = tensor`."""
 
     def unit_bwd(rec, dz_in, relu, want_dres, dgrad_residual=None, need_dx=True):
-        dy, dres, dg, db = L.bn_bwd(dz_in, rec.y, rec.z, rec.sv, rec.bn.weight, relu=relu, want_dres=want_dres)
+        # units without a residual input recompute the ReLU mask from y (rec.has_res False -> z not read)
+        dy, dres, dg, db = L.bn_bwd(dz_in, rec.y, rec.z if rec.has_res else None, rec.sv, rec.bn.weight, relu=relu,
+                                    want_dres=want_dres)
         if rec.bn.weight.requires_grad:
             grads[rec.bn.weight], grads[rec.bn.bias] = dg, db
         if rec.conv.weight.requires_grad:
