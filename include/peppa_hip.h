@@ -63,6 +63,10 @@ typedef struct pp_igemm_desc {
   float* colstats; int ldstat;           /* optional [ceil(M/128)][2][ldstat] partial col sums */
   int nbatch, inner;
   long long a_s0, a_s1, b_s0, b_s1, c_s0, c_s1, bias_s0, bias_s1;
+  /* optional output row map (conv modes): compact row (n, rt, rh, rw) is stored at row
+   * ((n*Ot + rt*os_t + oo_t)*Oh + rh*os_h + oo_h)*Ow + rw*os_w + oo_w of C (and read there from `residual`).
+   * Used by the parity-class decomposition of stride-2 data gradients. */
+  int omap, Ot, Oh, Ow, os_t, os_h, os_w, oo_t, oo_h, oo_w;
 } pp_igemm_desc;
 int pp_igemm(const pp_igemm_desc* d, pp_stream_t s);
 
@@ -87,6 +91,8 @@ int pp_wgrad(const pp_wgrad_desc* d, pp_stream_t s);
  * transpose_io=1 builds the dgrad operand [Ci][taps(flipped)][cog]. */
 int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, void* out, int rows_out, int cg,
                         int transpose_io, int flip, float scale, pp_stream_t s);
+/* out[r][i][cg] = w[r][sel[i]][cg] (bf16): tap subset of a conv operand, nsel <= 32 (sel is a HOST array) */
+int pp_select_taps(const void* w, int rows, int taps, int cg, const int* sel, int nsel, void* out, pp_stream_t s);
 /* g [Co][taps][cg] fp32 (pp_wgrad layout) -> dw [Co][Ci][taps] fp32, dw = g (beta=0) or += */
 int pp_unprep_conv_grad(const float* g, int Co, int Ci, int taps, int cg, float* dw, pp_stream_t s);
 /* generic 2-D fp32 -> bf16 copy with padding / transpose: out[r*ld_out + c] = in[r][c] (or in[c][r]) for

@@ -28,7 +28,9 @@ class IGemmDesc(C.Structure):
         ("bias", C.c_void_p), ("act", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int),
         ("colstats", C.c_void_p), ("ldstat", C.c_int), ("nbatch", C.c_int), ("inner", C.c_int),
         ("a_s0", C.c_longlong), ("a_s1", C.c_longlong), ("b_s0", C.c_longlong), ("b_s1", C.c_longlong),
-        ("c_s0", C.c_longlong), ("c_s1", C.c_longlong), ("bias_s0", C.c_longlong), ("bias_s1", C.c_longlong)]
+        ("c_s0", C.c_longlong), ("c_s1", C.c_longlong), ("bias_s0", C.c_longlong), ("bias_s1", C.c_longlong),
+        ("omap", C.c_int), ("Ot", C.c_int), ("Oh", C.c_int), ("Ow", C.c_int), ("os_t", C.c_int), ("os_h", C.c_int),
+        ("os_w", C.c_int), ("oo_t", C.c_int), ("oo_h", C.c_int), ("oo_w", C.c_int)]
 
 
 class WGradDesc(C.Structure):
@@ -54,6 +56,7 @@ SIGNATURES = {
     "pp_igemm": [C.POINTER(IGemmDesc), P],
     "pp_wgrad": [C.POINTER(WGradDesc), P],
     "pp_prep_conv_weight": [P, I, I, I, P, I, I, I, I, F, P],
+    "pp_select_taps": [P, I, I, I, C.POINTER(I), I, P, P],
     "pp_unprep_conv_grad": [P, I, I, I, I, P, P],
     "pp_cast_pad_2d": [P, I, I, I, P, I, I, I, I, P],
     "pp_cast_f32_to_bf16": [P, P, L, P],

@@ -103,6 +103,18 @@ __global__ void unprep_conv_kernel(const float* __restrict__ g, int Co, int Ci, 
   }
 }
 
+struct TapSel { int v[32]; };
+__global__ void select_taps_kernel(const uint4* __restrict__ w, int taps, int cg8, TapSel sel, int nsel, uint4* __restrict__ out,
+                                   long long n) {
+  GSTRIDE(i, n) {   // i over rows * nsel * cg8 16-byte chunks
+    const int c = (int)(i % cg8);
+    const long long t = i / cg8;
+    const int si = (int)(t % nsel);
+    const long long r = t / nsel;
+    out[i] = w[(r * taps + sel.v[si]) * cg8 + c];
+  }
+}
+
 // batched bf16 transpose through LDS: in [R][ld_in] (C cols) -> out [C][ld_out] (R cols, zero padded)
 __global__ __launch_bounds__(256) void transpose_kernel(const bfraw* __restrict__ in, long long in_bs, int ld_in,
                                                         bfraw* __restrict__ out, long long out_bs, int ld_out, int R, int C,
@@ -217,6 +229,18 @@ extern "C" int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, voi
   PP_CHECK_ARG(transpose_io ? (rows_out >= Ci && cg >= Co) : (rows_out >= Co && cg >= Ci), "pp_prep_conv_weight: pad too small");
   hipLaunchKernelGGL(prep_conv_kernel, dim3(sgrid((long long)rows_out * taps * cg)), dim3(256), 0, S_, w, Co, Ci, taps,
                      (bfraw*)out, rows_out, cg, transpose_io, flip, scale);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_select_taps(const void* w, int rows, int taps, int cg, const int* sel, int nsel, void* out, pp_stream_t s) {
+  PP_CHECK_ARG(rows > 0 && taps > 0 && cg > 0 && cg % 8 == 0 && nsel > 0 && nsel <= 32 && sel, "pp_select_taps: sizes");
+  TapSel ts;
+  for (int i = 0; i < nsel; ++i) {
+    PP_CHECK_ARG(sel[i] >= 0 && sel[i] < taps, "pp_select_taps: tap %d out of range", sel[i]);
+    ts.v[i] = sel[i];
+  }
+  const long long n = (long long)rows * nsel * (cg / 8);
+  hipLaunchKernelGGL(select_taps_kernel, dim3(sgrid(n)), dim3(256), 0, S_, (const uint4*)w, taps, cg / 8, ts, nsel, (uint4*)out, n);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -317,8 +317,18 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
         const int col = nb * BN + ch * 8;
         if (cid < 32 * WN && m < p.M && col < ncols_store) {
           uint4 v = *(const uint4*)(stg + row * STG_STRIDE + ch * 16);
+          long long orow = m;
+          if (MODE != PP_DENSE && p.omap) {   // scatter compact rows of a parity class into the full tensor
+            const uint32_t t1 = fdiv((uint32_t)m, rd.dRw);
+            const int rw = m - (int)t1 * g.Rw;
+            const uint32_t t2 = fdiv(t1, rd.dRh);
+            const int rh = (int)t1 - (int)t2 * g.Rh;
+            const int n = (int)fdiv(t2, rd.dRt);
+            const int rt = (int)t2 - n * g.Rt;
+            orow = (((long long)n * p.Ot + rt * p.os_t + p.oo_t) * p.Oh + rh * p.os_h + p.oo_h) * p.Ow + rw * p.os_w + p.oo_w;
+          }
           if (FULL && residual) {
-            const uint4 rv = *(const uint4*)(residual + c_off + (long long)m * p.ldr + col);
+            const uint4 rv = *(const uint4*)(residual + c_off + orow * p.ldr + col);
             float x[8], y[8];
             unpack8(v, x);
             unpack8(rv, y);
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
             for (int q = 0; q < 8; ++q) x[q] += y[q];
             v = pack8(x);
           }
-          *(uint4*)(Cout + c_off + (long long)m * p.ldc + col) = v;
+          *(uint4*)(Cout + c_off + orow * p.ldc + col) = v;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -472,6 +482,8 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   } else {
     PP_CHECK_ARG(!d.residual && !d.Cpre && !d.colstats, "pp_igemm: fp32 output supports bias/act only");
   }
+  if (d.omap) PP_CHECK_ARG(d.g.mode != PP_DENSE && !d.c_fp32 && !d.colstats && d.os_t > 0 && d.os_h > 0 && d.os_w > 0,
+                           "pp_igemm: the output row map needs a conv gather and a plain bf16 store");
   if (d.colstats) PP_CHECK_ARG(!d.bias && d.act == PP_ACT_NONE && !d.residual && !d.Cpre && d.nbatch == 1 && d.ldstat >= d.N,
                                "pp_igemm: colstats needs a plain epilogue (no bias/act/residual/pre) and nbatch 1");
   PP_CHECK_ARG(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.Bt & 15) == 0, "pp_igemm: operands must be 16-byte aligned");

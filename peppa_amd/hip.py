@@ -87,7 +87,7 @@ def profile_summary():
 
 def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NONE, residual=None, ldr=0,
           Cpre=None, colstats=None, ldstat=0, nbatch=1, inner=1, a_s=(0, 0), b_s=(0, 0), c_s=(0, 0),
-          bias_s=(0, 0)):
+          bias_s=(0, 0), omap=None):
     d = IGemmDesc()
     d.M, d.N, d.K, d.g = M, N, K, g
     d.A, d.Bt, d.ldb, d.b_rows = _p(A, bf16), _p(Bt, bf16), ldb, b_rows
@@ -101,6 +101,9 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
     d.b_s0, d.b_s1 = b_s
     d.c_s0, d.c_s1 = c_s
     d.bias_s0, d.bias_s1 = bias_s
+    if omap is not None:  # ((Ot, Oh, Ow), (scale t,h,w), (offset t,h,w))
+        d.omap = 1
+        (d.Ot, d.Oh, d.Ow), (d.os_t, d.os_h, d.os_w), (d.oo_t, d.oo_h, d.oo_w) = omap
     _profiled(f"igemm_kernel<{_MODE_NAMES[g.mode]}> N={N} K={K}", 2.0 * M * N * K * nbatch,
               lambda: call("pp_igemm", C.byref(d), _s()))
 
@@ -119,6 +122,11 @@ def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=
 def prep_conv_weight(w, out, Co, Ci, taps, rows_out, cg, transpose_io=False, flip=False, scale=1.0):
     call("pp_prep_conv_weight", _p(w, f32), Co, Ci, taps, _p(out, bf16), rows_out, cg, int(transpose_io), int(flip),
          scale, _s())
+
+
+def select_taps(w, out, rows, taps, cg, sel):
+    arr = (C.c_int * len(sel))(*sel)
+    call("pp_select_taps", _p(w, bf16), rows, taps, cg, arr, len(sel), _p(out, bf16), _s())
 
 
 def unprep_conv_grad(g, dw, Co, Ci, taps, cg):

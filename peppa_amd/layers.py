@@ -94,8 +94,49 @@ def conv_fwd(x, geom, wf, *, stats=False, bias=None, act=H.ACT_NONE, out=None, p
     return y, partials
 
 
+def _parity_classes(geom):
+    """Stride-2 data gradient = one dense unit-stride problem per output-parity class: positions r = s*r' + q
+    only see taps d = d0 + s*i with d0 = (q + p) mod s, and read dY at r' + (q + p - d0)/s - i."""
+    import itertools
+    dims = list(zip((geom.Ti, geom.Hi, geom.Wi), geom.k, geom.s, geom.p))
+    per_dim = []
+    for R, k, s, p in dims:
+        opts = []
+        for q in range(s):
+            d0 = (q + p) % s
+            taps = list(range(d0, k, s))
+            Rc = (R - q + s - 1) // s if R > q else 0
+            opts.append((q, taps, (q + p - d0) // s, Rc))
+        per_dim.append(opts)
+    return list(itertools.product(*per_dim))
+
+
+def _conv_dgrad_strided(dy, geom, wd, residual):
+    classes = _parity_classes(geom)
+    empty_class = any(len(t) == 0 for cls in classes for (_, t, _, _) in cls)
+    assert not (empty_class and residual is not None)
+    dx = (zeros if empty_class else empty)((geom.Min, geom.in_cstride), bf16, dy)
+    kt, kh, kw = geom.k
+    for cls in classes:
+        (qt, tt, ct, Rt), (qh, th, ch, Rh), (qw, tw, cw, Rw) = cls
+        if not (tt and th and tw) or Rt * Rh * Rw == 0:
+            continue
+        sel = [(a * kh + b) * kw + c for a in tt for b in th for c in tw]
+        wsel = empty((geom.Ci, len(sel), geom.cg_out), bf16, dy)
+        H.select_taps(wd, wsel, geom.Ci, geom.taps, geom.cg_out, sel)
+        g = H.gather_conv(H.CONV_DGRAD, (Rt, Rh, Rw), (geom.To, geom.Ho, geom.Wo), (len(tt), len(th), len(tw)), (1, 1, 1),
+                          (ct, ch, cw), geom.cg_out, geom.out_cstride)
+        K = len(sel) * geom.cg_out
+        H.igemm(dy, wsel, dx, geom.B * Rt * Rh * Rw, geom.in_cstride, K, g, K, geom.in_cstride, b_rows=geom.Ci,
+                residual=residual, ldr=geom.in_cstride,
+                omap=((geom.Ti, geom.Hi, geom.Wi), geom.s, (qt, qh, qw)))
+    return dx
+
+
 def conv_dgrad(dy, geom, wd, *, residual=None):
     """dx[Min][in_cstride] = conv^T(dy) (+ residual)."""
+    if geom.groups == 1 and max(geom.s) == 2:
+        return _conv_dgrad_strided(dy, geom, wd, residual)
     dx = empty((geom.Min, geom.in_cstride), bf16, dy)
     if geom.groups == 1:
         H.igemm(dy, wd, dx, geom.Min, geom.in_cstride, geom.Kd, geom.g_dgrad(), geom.Kd, geom.in_cstride,
