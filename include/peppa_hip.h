@@ -115,6 +115,11 @@ int pp_fill_f32(float* p, float v, long long n, pp_stream_t s);
 int pp_video_normalize_ndhwc(const float* x, void* out, int B, int T, int H, int W,
                              const float* mean3 /* HOST */, const float* std3 /* HOST */, pp_stream_t s);
 
+/* MaxPool2d(3, 2, 1) of torchvision resnet18 (static ImageEncoder, pig/models.py:181-186) on channels-last
+ * bf16 [N][H][W][Cp]; the backward routes each window's gradient to its first maximum (PyTorch's rule) */
+int pp_maxpool3x3s2_fwd(const void* x, void* y, int N, int H, int W, int Cp, pp_stream_t s);
+int pp_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int Cp, pp_stream_t s);
+
 /* ---- BatchNorm3d (train mode) : torchvision BN layers inside R3DEncoder ---------------- */
 /* reduce igemm colstats partials -> mean, rstd, scale=gamma*rstd, shift=beta-mean*scale;
  * updates running stats (momentum, unbiased var). C real channels, Cp padded (scale/shift=0). */

@@ -281,3 +281,91 @@ extern "C" int pp_colsum_bf16(const void* x, long long M, int N, int ld, float* 
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
+
+// ---- MaxPool (1,3,3)/(1,2,2)/(0,1,1) on channels-last bf16 (torchvision resnet18.maxpool, pig/models.py:185) ----
+namespace {
+__device__ __forceinline__ void max8(float* m, const float* v) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], v[q]);
+}
+__global__ void maxpool_fwd_kernel(const bfraw* __restrict__ x, bfraw* __restrict__ y, int N, int H, int W, int Ho, int Wo,
+                                   int cpr) {
+  GSTRIDE(i, (long long)N * Ho * Wo * cpr) {
+    const int c = (int)(i % cpr);
+    long long t = i / cpr;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const long long n = t / Ho;
+    float m[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] = -3.0e38f;
+    for (int dy = 0; dy < 3; ++dy)
+      for (int dx = 0; dx < 3; ++dx) {
+        const int yi = yo * 2 - 1 + dy, xi = xo * 2 - 1 + dx;
+        if ((unsigned)yi < (unsigned)H && (unsigned)xi < (unsigned)W) {
+          float v[8];
+          unpack8(*(const uint4*)(x + (((n * H + yi) * W + xi) * cpr + c) * 8), v);
+          max8(m, v);
+        }
+      }
+    *(uint4*)(y + i * 8) = pack8(m);
+  }
+}
+// gather form of the backward: an input position receives dY of every window whose FIRST maximum it is
+__global__ void maxpool_bwd_kernel(const bfraw* __restrict__ x, const bfraw* __restrict__ dy, bfraw* __restrict__ dx, int N,
+                                   int H, int W, int Ho, int Wo, int cpr) {
+  GSTRIDE(i, (long long)N * H * W * cpr) {
+    const int c = (int)(i % cpr);
+    long long t = i / cpr;
+    const int xi = (int)(t % W); t /= W;
+    const int yi = (int)(t % H);
+    const long long n = t / H;
+    float self[8], acc[8];
+    unpack8(*(const uint4*)(x + i * 8), self);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int yo = (yi + 1) / 2 - ((yi + 1) % 2 == 0 ? 1 : 0); yo <= (yi + 1) / 2; ++yo) {
+      if ((unsigned)yo >= (unsigned)Ho) continue;
+      for (int xo = (xi + 1) / 2 - ((xi + 1) % 2 == 0 ? 1 : 0); xo <= (xi + 1) / 2; ++xo) {
+        if ((unsigned)xo >= (unsigned)Wo) continue;
+        // is (yi, xi) the first maximum of window (yo, xo)?  before = strictly-greater needed, after = greater-or-equal
+        bool first[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) first[q] = true;
+        for (int dyy = 0; dyy < 3; ++dyy)
+          for (int dxx = 0; dxx < 3; ++dxx) {
+            const int y2 = yo * 2 - 1 + dyy, x2 = xo * 2 - 1 + dxx;
+            if ((unsigned)y2 >= (unsigned)H || (unsigned)x2 >= (unsigned)W || (y2 == yi && x2 == xi)) continue;
+            float v[8];
+            unpack8(*(const uint4*)(x + (((n * H + y2) * W + x2) * cpr + c) * 8), v);
+            const bool before = (y2 < yi) || (y2 == yi && x2 < xi);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) first[q] = first[q] && (before ? (v[q] < self[q]) : (v[q] <= self[q]));
+          }
+        float g[8];
+        unpack8(*(const uint4*)(dy + (((n * Ho + yo) * Wo + xo) * cpr + c) * 8), g);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += first[q] ? g[q] : 0.f;
+      }
+    }
+    *(uint4*)(dx + i * 8) = pack8(acc);
+  }
+}
+}  // namespace
+
+extern "C" int pp_maxpool3x3s2_fwd(const void* x, void* y, int N, int H, int W, int Cp, pp_stream_t s) {
+  PP_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "pp_maxpool3x3s2_fwd: sizes");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(sgrid((long long)N * Ho * Wo * (Cp / 8))), dim3(256), 0, S_, (const bfraw*)x,
+                     (bfraw*)y, N, H, W, Ho, Wo, Cp / 8);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int Cp, pp_stream_t s) {
+  PP_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "pp_maxpool3x3s2_bwd: sizes");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(sgrid((long long)N * H * W * (Cp / 8))), dim3(256), 0, S_, (const bfraw*)x,
+                     (const bfraw*)dy, (bfraw*)dx, N, H, W, Ho, Wo, Cp / 8);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

@@ -166,6 +166,14 @@ def video_normalize_ndhwc(x, out, mean3, std3):
     call("pp_video_normalize_ndhwc", _p(x, f32), _p(out, bf16), B, T, H, W, m, sd, _s())
 
 
+def maxpool3x3s2_fwd(x, y, N, Hh, W, Cp):
+    call("pp_maxpool3x3s2_fwd", _p(x, bf16), _p(y, bf16), N, Hh, W, Cp, _s())
+
+
+def maxpool3x3s2_bwd(x, dy, dx, N, Hh, W, Cp):
+    call("pp_maxpool3x3s2_bwd", _p(x, bf16), _p(dy, bf16), _p(dx, bf16), N, Hh, W, Cp, _s())
+
+
 # ---- batch norm -----------------------------------------------------------------------------------
 def bn_finalize(partials, nblk, ldstat, count, Cn, Cp, gamma, beta, eps, momentum, rmean, rvar, mean, rstd,
                 scale, shift, ws=None):

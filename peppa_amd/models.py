@@ -209,9 +209,36 @@ class R3DEncoder(nn.Module):
 
 
 class ImageEncoder(nn.Module):
+    """Static (per-frame) encoder of hparams_static.yaml: resnet18 trunk on every frame, pooled over time."""
+
     def __init__(self, pretrained=True, project=True, pooling='average'):
         super().__init__()
-        _hip_todo("the static ImageEncoder (hparams_static.yaml, resnet18 per frame)")
+        self.pretrained = pretrained
+        if pretrained:
+            logging.warning("video.pretrained=true: ImageNet weights cannot be downloaded offline; using random "
+                            "init with the imagenet normalisation constants (load a state_dict to override)")
+        self.image = V.ResNet18()
+        for param in self.image.fc.parameters():
+            param.requires_grad = False
+        self.project = nn.Linear(512, 512) if project else nn.Identity()
+        self.norm_kind = "imagenet" if self.pretrained else "peppa"
+        self.transform = build_transform(self.norm_kind)
+        if pooling == 'attention':
+            self.pool = Attention(512, 128)
+        elif pooling == 'average':
+            self.pool = lambda x: _hip_todo("static video pooling 'average'")
+        else:
+            raise ValueError(f"Invalid pooling {pooling}")
+
+    @property
+    def video(self):   # VideoTrunkFn reads `.video` (the trunk) and `.norm_kind`
+        return self.image
+
+    def forward(self, x):
+        feats = VideoTrunkFn.apply(x, self, torch.is_grad_enabled(), *self.image.trunk_parameters())
+        if isinstance(self.pool, Attention) and isinstance(self.project, nn.Linear):
+            return self.pool.pooled_projected(feats, self.project)
+        _hip_todo("static video head other than attention pooling + projection")
 
 
 class VideoAveragePool(nn.Module):

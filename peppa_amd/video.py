@@ -127,10 +127,75 @@ class VideoResNet(nn.Module):
         return ps
 
 
+class BasicBlock2D(nn.Module):
+    def __init__(self, ci, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(ci, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+
+class ResNet18(nn.Module):
+    """torchvision.models.resnet18 parameter tree (`conv1, bn1, layer1..4, fc`), used per frame by the
+    static ImageEncoder (pig/models.py:156-200).  Executed as (1,k,k) 3-D convolutions over [B][T][H][W]."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self._inplanes = 64
+        self.layer1 = self._make_layer(64, 1)
+        self.layer2 = self._make_layer(128, 2)
+        self.layer3 = self._make_layer(256, 2)
+        self.layer4 = self._make_layer(512, 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512, 1000)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, stride):
+        ds = None
+        if stride != 1 or self._inplanes != planes:
+            ds = nn.Sequential(nn.Conv2d(self._inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        blocks = [BasicBlock2D(self._inplanes, planes, stride, ds), BasicBlock2D(planes, planes)]
+        self._inplanes = planes
+        return nn.Sequential(*blocks)
+
+    def units(self):
+        plan = [("unit", self.conv1, self.bn1, True), ("maxpool",)]
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                plan += [("block_begin", blk.downsample), ("unit", blk.conv1, blk.bn1, True),
+                         ("block_last", blk.conv2, blk.bn2, blk.downsample)]
+        return plan
+
+    def trunk_parameters(self):
+        ps = []
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
+                ps += list(m.parameters(recurse=False))
+        return ps
+
+
+def _t3(v):
+    """Conv2d modules (resnet18, static ImageEncoder) run as 3-D convolutions with a unit time tap."""
+    return tuple(v) if len(v) == 3 else (1,) + tuple(v)
+
+
 def _geom(conv, B, thw, first=False):
     ci = conv.in_channels
     kw = dict(in_cstride=8, cg_in=8) if first else {}
-    return L.ConvGeom(B, thw, ci, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, **kw)
+    pad = conv.padding if len(conv.padding) == 3 else (0,) + tuple(conv.padding)
+    return L.ConvGeom(B, thw, ci, conv.out_channels, _t3(conv.kernel_size), _t3(conv.stride), pad, **kw)
 
 
 class _Tape:
@@ -173,6 +238,14 @@ def run_plan(plan, cur, thw, B, training, save, first=False):
             cur, thw, rec = run_unit(conv, bn, relu, cur, thw, first=first)
             first = False
             tape.append(("unit", rec))
+        elif item[0] == "maxpool":
+            T, Hh, W = thw
+            Cp = cur.shape[1]
+            Ho, Wo = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
+            out = L.empty((B * T * Ho * Wo, Cp), bf16, cur)
+            H.maxpool3x3s2_fwd(cur, out, B * T, Hh, W, Cp)
+            tape.append(("maxpool", (cur, B * T, Hh, W, Cp) if save else None))
+            cur, thw = out, (T, Ho, Wo)
         elif item[0] == "block_begin":
             block_in, block_thw = cur, thw
             tape.append(("block_begin", None))
@@ -209,6 +282,12 @@ def trunk_backward(tape, dz, grads):
         kind = tape[i][0]
         if kind == "unit":
             cur, _ = unit_bwd(tape[i][1], cur, tape[i][1].relu, False)
+            i -= 1
+        elif kind == "maxpool":
+            x, N, Hh, W, Cp = tape[i][1]
+            dx = L.empty(x.shape, bf16, x)
+            H.maxpool3x3s2_bwd(x, cur, dx, N, Hh, W, Cp)
+            cur = dx
             i -= 1
         elif kind == "block_last":
             _, rec, ds_rec = tape[i]

@@ -488,3 +488,21 @@ def test_bertadam_golden(golden_dir):
     for i in range(5):
         np.testing.assert_allclose(ms[i].cpu().numpy(), d[f"m_{i}"], atol=1e-6)
         np.testing.assert_allclose(vs[i].cpu().numpy(), d[f"v_{i}"], rtol=5e-5, atol=1e-9)  # fma vs mul+add over 6 steps
+
+
+def test_maxpool_3x3s2_with_ties():
+    g = torch.Generator().manual_seed(12)
+    N, C, Hh, W = 3, 16, 9, 12
+    x = torch.randint(-3, 4, (N, C, Hh, W), generator=g).float().requires_grad_()   # small integers -> many ties
+    y_ref = F.max_pool2d(x, 3, 2, 1)
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    xc = x.detach().permute(0, 2, 3, 1).reshape(-1, C).to(torch.bfloat16).to(DEV).contiguous()
+    Ho, Wo = y_ref.shape[2:]
+    y = torch.empty(N * Ho * Wo, C, dtype=torch.bfloat16, device=DEV)
+    H.maxpool3x3s2_fwd(xc, y, N, Hh, W, C)
+    dx = torch.empty_like(xc)
+    H.maxpool3x3s2_bwd(xc, dy.permute(0, 2, 3, 1).reshape(-1, C).to(torch.bfloat16).to(DEV).contiguous(), dx, N, Hh, W, C)
+    torch.cuda.synchronize()
+    assert torch.equal(y.float().cpu().reshape(N, Ho, Wo, C).permute(0, 3, 1, 2), y_ref.detach())
+    close(dx.float().cpu().reshape(N, Hh, W, C).permute(0, 3, 1, 2), x.grad, rtol=1e-2, name="maxpool bwd")

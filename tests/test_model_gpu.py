@@ -278,3 +278,37 @@ def test_api_surface_and_errors():
     assert (cm - O.cosine_matrix(out.video.cpu(), out.audio.cpu())).abs().max() < 1e-5
     tri = pig.triplet.score_triplets(out.video.repeat(4, 1), out.audio.repeat(4, 1), torch.tensor([1., 1, 2, 2, 1, 1, 2, 2]), n_samples=3)
     assert tri.shape == (3,)
+
+
+def test_static_image_encoder_c1_config():
+    """BASELINE configs[0]: hparams_static.yaml, 8x64x64 frames + 1 s @ 16 kHz audio, batch 4."""
+    import os
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "hparams_static.yaml")))
+    cfg["audio"]["pretrained"] = False
+    ref, net = build_pair(cfg)
+    ref.train(); net.train()
+    batch = synthetic_batch(4, 8, 64, 16000)
+    with torch.no_grad():
+        V32 = ref.encode_video(batch.video)
+        sd = copy.deepcopy(ref.state_dict())
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            V16 = ref.encode_video(batch.video).float()
+        ref.load_state_dict(sd)
+    gb = batch.to(DEV)
+    loss = net.training_step(gb, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    used = [n for n, p in net.named_parameters() if not n.startswith("video_encoder.image.fc")]
+    named = dict(net.named_parameters())
+    assert all(named[n].grad is not None and torch.isfinite(named[n].grad).all() for n in used)
+    assert net.video_encoder.image.fc.weight.grad is None
+    with torch.no_grad():
+        Vh = net.encode_video(gb.video).cpu()
+    yard = 1 - F.cosine_similarity(V16, V32, dim=1).min().item()
+    ours = 1 - F.cosine_similarity(Vh, V32, dim=1).min().item()
+    print(f"static video 1-cos: HIP {ours:.5f} vs torch bf16 autocast of the oracle {yard:.5f}")
+    assert (Vh.norm(dim=1) - 1).abs().max() < 1e-4
+    assert ours <= 1.5 * yard + 2e-3
