@@ -154,6 +154,10 @@ int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* m
 int pp_gelu_fwd(const void* x, void* y, long long n, pp_stream_t s);
 int pp_gelu_bwd(const void* dy, const void* x, void* dx, long long n, pp_stream_t s);
 int pp_add_bf16(const void* a, const void* b, void* out, long long n, pp_stream_t s);
+/* dropout with a counter-based mask (seed, element index): y = keep ? x/(1-p) : 0 (+ res).  Calling it again with
+ * the same seed on the gradient is the backward pass.  n multiple of 8; x and y may alias. */
+int pp_dropout_bf16(const void* x, const void* res, void* y, long long n, float p, unsigned seed, pp_stream_t s);
+int pp_dropout_f32(const float* x, float* y, long long n, float p, unsigned seed, pp_stream_t s);
 /* per-column sums of a bf16 matrix [M][ld] -> fp32 out[N] (bias gradients); out is overwritten */
 int pp_colsum_bf16(const void* x, long long M, int N, int ld, float* out, pp_stream_t s);
 

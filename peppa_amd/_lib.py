@@ -77,6 +77,8 @@ SIGNATURES = {
     "pp_gelu_fwd": [P, P, L, P],
     "pp_gelu_bwd": [P, P, P, L, P],
     "pp_add_bf16": [P, P, P, L, P],
+    "pp_dropout_bf16": [P, P, P, L, F, C.c_uint, P],
+    "pp_dropout_f32": [P, P, L, F, C.c_uint, P],
     "pp_colsum_bf16": [P, L, I, I, P, P],
     "pp_layernorm_fwd": [P, P, P, F, P, P, P, I, I, P],
     "pp_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, P],

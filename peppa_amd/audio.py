@@ -9,8 +9,9 @@ The torch.nn modules are parameter containers; forward/backward are hand-schedul
 kernels (strided-GEMM conv stack, grouped positional conv, MFMA GEMMs with bias/GELU/residual
 epilogues, LayerNorm, batched attention) driven by `Wav2Vec2Fn`.
 
-Dropout / LayerDrop: the reference trains with p=0.1; this path currently runs them at p=0
-(identity) -- see DESIGN.md "Deviations".
+Dropout / LayerDrop follow the modules' `p` / `layer_drop` in train mode (torchaudio defaults 0.1): masks
+come from a counter-based hash (seed, element index) and are regenerated in the backward pass; LayerDrop
+uses the host RNG like torchaudio (`torch.rand(1).item() <= layer_drop`).  Parity tests set p = 0.
 """
 import torch
 from torch import nn
@@ -162,6 +163,21 @@ class _Rec:
     pass
 
 
+class _Drop:
+    """Per-forward dropout bookkeeping: one fresh seed per dropout site."""
+
+    def __init__(self, training):
+        self.on = training
+        self.base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if training else 0
+        self.n = 0
+
+    def site(self, module):
+        """(p, seed) for one dropout site; p = 0 when not training."""
+        p = float(module.p) if (self.on and module is not None) else 0.0
+        self.n += 1
+        return p, (self.base + self.n * 0x9E3779B1) & 0xffffffff
+
+
 # ---------------------------------------------------------------------------------------------------
 def _fe_forward(fe, wave, save):
     """wave fp32 [B][L] -> features bf16 [B*T][512]; tape for backward."""
@@ -226,8 +242,8 @@ def _prep_qkv(att, need_dgrad):
     return wf, wt, bias
 
 
-def _attention_fwd(qkv, B, T, Tp, scale, save):
-    """qkv bf16 [B*T][2304] -> ctx bf16 [B*T][768]; returns saved P."""
+def _attention_fwd(qkv, B, T, Tp, scale, save, drop=(0.0, 0)):
+    """qkv bf16 [B*T][2304] -> ctx bf16 [B*T][768]; returns saved P (before attention dropout)."""
     Hn, Dh, D3 = NUM_HEADS, 64, 2304
     nb = B * Hn
     S = L.empty((nb, T, Tp), f32, qkv)
@@ -238,13 +254,17 @@ def _attention_fwd(qkv, B, T, Tp, scale, save):
     H.softmax_fwd(S, Tp, P, Tp, nb, T, scale)
     Vt = L.empty((nb, Dh, Tp), bf16, qkv)
     H.transpose_bf16(v, T * D3, D3, Vt, Hn * Dh * Tp, Tp, nb, T, Dh, inner=Hn, in_s1=Dh, out_s1=Dh * Tp)
+    Pd = P
+    if drop[0] > 0:
+        Pd = L.empty(P.shape, bf16, qkv)
+        H.dropout_bf16(P, Pd, drop[0], drop[1])
     ctx = L.empty((B * T, 768), bf16, qkv)
-    H.igemm(P, Vt, ctx, T, Dh, Tp, H.gather_dense(Tp), Tp, 768, nbatch=nb, inner=Hn, a_s=(Hn * T * Tp, T * Tp),
+    H.igemm(Pd, Vt, ctx, T, Dh, Tp, H.gather_dense(Tp), Tp, 768, nbatch=nb, inner=Hn, a_s=(Hn * T * Tp, T * Tp),
             b_s=(Hn * Dh * Tp, Dh * Tp), c_s=(T * 768, Dh))
     return ctx, (P if save else None)
 
 
-def _attention_bwd(dctx, qkv, P, B, T, Tp, scale):
+def _attention_bwd(dctx, qkv, P, B, T, Tp, scale, drop=(0.0, 0)):
     """-> dqkv bf16 [B*T][2304]."""
     Hn, Dh, D3 = NUM_HEADS, 64, 2304
     nb = B * Hn
@@ -255,9 +275,14 @@ def _attention_bwd(dctx, qkv, P, B, T, Tp, scale):
     dP = L.empty((nb, T, Tp), f32, qkv)
     H.igemm(dctx, v, dP, T, T, Dh, H.gather_dense(768), D3, Tp, nbatch=nb, inner=Hn, a_s=(T * 768, Dh),
             b_s=(T * D3, Dh), c_s=(Hn * T * Tp, T * Tp))
-    # dV = P^T dctx
+    Pd = P
+    if drop[0] > 0:   # same mask as the forward pass: dP through the dropout, dV from the dropped probabilities
+        H.dropout_f32(dP, dP, drop[0], drop[1])
+        Pd = L.empty(P.shape, bf16, qkv)
+        H.dropout_bf16(P, Pd, drop[0], drop[1])
+    # dV = Pd^T dctx
     Pt = L.empty((nb, T, Tp), bf16, qkv)
-    H.transpose_bf16(P, T * Tp, Tp, Pt, T * Tp, Tp, nb, T, T)
+    H.transpose_bf16(Pd, T * Tp, Tp, Pt, T * Tp, Tp, nb, T, T)
     dOt = L.empty((nb, Dh, Tp), bf16, qkv)
     H.transpose_bf16(dctx, T * 768, 768, dOt, Hn * Dh * Tp, Tp, nb, T, Dh, inner=Hn, in_s1=Dh, out_s1=Dh * Tp)
     H.igemm(Pt, dOt, dv, T, Dh, Tp, H.gather_dense(Tp), Tp, D3, nbatch=nb, inner=Hn, a_s=(Hn * T * Tp, T * Tp),
@@ -280,7 +305,7 @@ def _attention_bwd(dctx, qkv, P, B, T, Tp, scale):
     return dqkv
 
 
-def _enc_forward(enc, feat, B, T, save):
+def _enc_forward(enc, feat, B, T, save, training=False):
     """feat bf16 [B*T][512] -> out fp32 [B*T][num_out]; tape."""
     M = B * T
     Tp = L.cpad(T)
@@ -292,6 +317,10 @@ def _enc_forward(enc, feat, B, T, save):
     t.xln = xln
     wf, t.proj_wt = L.prep_linear(fp.projection.weight, need_dgrad=save)
     x0 = L.linear_fwd(xln, M, wf, 768, bias=fp.projection.bias)
+    drop = _Drop(training)
+    t.d_fp = drop.site(fp.dropout)
+    if t.d_fp[0] > 0:
+        H.dropout_bf16(x0, x0, *t.d_fp)
     # positional conv (weight-normalised, grouped), GELU, + residual
     pc = tr.pos_conv_embed
     conv = pc.conv
@@ -308,25 +337,44 @@ def _enc_forward(enc, feat, B, T, save):
             b_s=(geom.Cog * geom.Kf, 0), c_s=(geom.Cog, 0), bias_s=(geom.Cog, 0))
     t.x0, t.x1, t.wfp = x0, x1, wfp
     x, t.ln1 = L.layernorm_fwd(x1, tr.layer_norm, tr.layer_norm.eps)
+    t.d_tr = drop.site(tr.dropout)
+    if t.d_tr[0] > 0:
+        H.dropout_bf16(x, x, *t.d_tr)
     t.layers = []
     for layer in tr.layers:
+        if training and tr.layer_drop > 0 and torch.rand(1).item() <= tr.layer_drop:
+            continue   # LayerDrop: the layer is skipped for this step (host RNG, like torchaudio)
         r = _Rec()
         att, ff = layer.attention, layer.feed_forward
+        r.d_att, r.d_out = drop.site(att.dropout), drop.site(layer.dropout)
+        r.d_int, r.d_ffo = drop.site(ff.intermediate_dropout), drop.site(ff.output_dropout)
         wf, r.qkv_wt, bqkv = _prep_qkv(att, save)
         r.x_in = x
         qkv = L.linear_fwd(x, M, wf, 2304, bias=bqkv)
-        ctx, r.P = _attention_fwd(qkv, B, T, Tp, att.scaling, save)
+        ctx, r.P = _attention_fwd(qkv, B, T, Tp, att.scaling, save, r.d_att)
         r.qkv, r.ctx = qkv, ctx
         wf, r.out_wt = L.prep_linear(att.out_proj.weight, need_dgrad=save)
-        s1 = L.linear_fwd(ctx, M, wf, 768, bias=att.out_proj.bias, residual=x)
+        if r.d_out[0] > 0:
+            t1 = L.linear_fwd(ctx, M, wf, 768, bias=att.out_proj.bias)
+            s1 = L.empty(t1.shape, bf16, t1)
+            H.dropout_bf16(t1, s1, *r.d_out, res=x)
+        else:
+            s1 = L.linear_fwd(ctx, M, wf, 768, bias=att.out_proj.bias, residual=x)
         xa, r.lnA = L.layernorm_fwd(s1, layer.layer_norm, layer.layer_norm.eps)
         r.s1, r.xa = s1, xa
         wf, r.ff1_wt = L.prep_linear(ff.intermediate_dense.weight, need_dgrad=save)
         r.u = L.empty((M, 3072), bf16, feat) if save else None
         h = L.linear_fwd(xa, M, wf, 3072, bias=ff.intermediate_dense.bias, act=H.ACT_GELU, pre=r.u)
+        if r.d_int[0] > 0:
+            H.dropout_bf16(h, h, *r.d_int)
         r.h = h
         wf, r.ff2_wt = L.prep_linear(ff.output_dense.weight, need_dgrad=save)
-        s2 = L.linear_fwd(h, M, wf, 768, bias=ff.output_dense.bias, residual=xa)
+        if r.d_ffo[0] > 0:
+            t2 = L.linear_fwd(h, M, wf, 768, bias=ff.output_dense.bias)
+            s2 = L.empty(t2.shape, bf16, t2)
+            H.dropout_bf16(t2, s2, *r.d_ffo, res=xa)
+        else:
+            s2 = L.linear_fwd(h, M, wf, 768, bias=ff.output_dense.bias, residual=xa)
         x, r.lnB = L.layernorm_fwd(s2, layer.final_layer_norm, layer.final_layer_norm.eps)
         r.s2, r.layer = s2, layer
         t.layers.append(r)
@@ -369,16 +417,26 @@ def _enc_backward(enc, t, dout, grads):
         layer = r.layer
         att, ff = layer.attention, layer.feed_forward
         ds2 = _ln_bwd(grads, layer.final_layer_norm, dx, r.s2, r.lnB)
-        _lin_grads(grads, ff.output_dense, r.h, ds2, M, 768, 3072)
-        dh = L.linear_dgrad(ds2, M, r.ff2_wt, 3072)
+        dt2 = ds2
+        if r.d_ffo[0] > 0:
+            dt2 = L.empty(ds2.shape, bf16, ds2)
+            H.dropout_bf16(ds2, dt2, *r.d_ffo)
+        _lin_grads(grads, ff.output_dense, r.h, dt2, M, 768, 3072)
+        dh = L.linear_dgrad(dt2, M, r.ff2_wt, 3072)
+        if r.d_int[0] > 0:
+            H.dropout_bf16(dh, dh, *r.d_int)
         du = L.empty(dh.shape, bf16, dh)
         H.gelu_bwd(dh, r.u, du)
         _lin_grads(grads, ff.intermediate_dense, r.xa, du, M, 3072, 768)
         dxa = L.linear_dgrad(du, M, r.ff1_wt, 768, residual=ds2)
         ds1 = _ln_bwd(grads, layer.layer_norm, dxa, r.s1, r.lnA)
-        _lin_grads(grads, att.out_proj, r.ctx, ds1, M, 768, 768)
-        dctx = L.linear_dgrad(ds1, M, r.out_wt, 768)
-        dqkv = _attention_bwd(dctx, r.qkv, r.P, B, T, Tp, att.scaling)
+        dt1 = ds1
+        if r.d_out[0] > 0:
+            dt1 = L.empty(ds1.shape, bf16, ds1)
+            H.dropout_bf16(ds1, dt1, *r.d_out)
+        _lin_grads(grads, att.out_proj, r.ctx, dt1, M, 768, 768)
+        dctx = L.linear_dgrad(dt1, M, r.out_wt, 768)
+        dqkv = _attention_bwd(dctx, r.qkv, r.P, B, T, Tp, att.scaling, r.d_att)
         # q/k/v projections share one fused weight gradient
         need = any(p.requires_grad for p in (att.q_proj.weight, att.k_proj.weight, att.v_proj.weight))
         if need:
@@ -388,6 +446,8 @@ def _enc_backward(enc, t, dout, grads):
                     grads[lin.weight] = dw[i * 768:(i + 1) * 768]
                     grads[lin.bias] = db[i * 768:(i + 1) * 768]
         dx = L.linear_dgrad(dqkv, M, r.qkv_wt, 768, residual=ds1)
+    if t.d_tr[0] > 0:
+        H.dropout_bf16(dx, dx, *t.d_tr)
     dx1 = _ln_bwd(grads, tr.layer_norm, dx, t.x1, t.ln1)
     # x1 = x0 + gelu(posconv(x0) + b)
     pc = tr.pos_conv_embed
@@ -414,6 +474,8 @@ def _enc_backward(enc, t, dout, grads):
     dx0 = L.empty((M, 768), bf16, du)
     H.igemm(du, wd, dx0, M, Cig, geom.Kd, geom.g_dgrad(), geom.Kd, 768, b_rows=Cig, residual=dx1, ldr=768,
             nbatch=pc.groups, inner=1, a_s=(geom.Cog, 0), b_s=(Cig * geom.Kd, 0), c_s=(Cig, 0))
+    if t.d_fp[0] > 0:
+        H.dropout_bf16(dx0, dx0, *t.d_fp)
     _lin_grads(grads, fp.projection, t.xln, dx0, M, 768, 512)
     dxln = L.linear_dgrad(dx0, M, t.proj_wt, 512)
     return _ln_bwd(grads, fp.layer_norm, dxln, t.feat, t.ln0)
@@ -433,7 +495,7 @@ class Wav2Vec2Fn(torch.autograd.Function):
         with torch.no_grad():
             feat, T, fe_tape = _fe_forward(fe, wave, save and any(p.requires_grad for p in fe.parameters()))
             if full:
-                out, enc_tape = _enc_forward(model.encoder, feat, B, T, save)
+                out, enc_tape = _enc_forward(model.encoder, feat, B, T, save, training=model.training)
                 result = out.view(B, T, -1)
             else:
                 enc_tape = None

@@ -369,3 +369,64 @@ extern "C" int pp_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int 
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
+
+// ---- dropout (torchaudio wav2vec2 components: feature projection, transformer, attention, feed-forward) ------
+// Counter-based mask: element i is kept iff hash16(seed, i) >= p * 65536; the same (seed, i) regenerates the
+// mask in the backward pass, so no mask tensor is stored.  y = keep ? x / (1 - p) : 0  (+ res).
+namespace {
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ void keep8(uint32_t seed, long long chunk, uint32_t thr, bool* keep) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t h = mix32((uint32_t)(chunk * 4 + q) * 0x9E3779B9u + seed + (uint32_t)((chunk * 4 + q) >> 32) * 0x7F4A7C15u);
+    keep[2 * q] = (h & 0xffffu) >= thr;
+    keep[2 * q + 1] = (h >> 16) >= thr;
+  }
+}
+__global__ void dropout_bf16_kernel(const bfraw* __restrict__ x, const bfraw* __restrict__ res, bfraw* __restrict__ y, long long nch,
+                                    uint32_t thr, float scale, uint32_t seed) {
+  GSTRIDE(i, nch) {
+    float f[8], r[8];
+    bool keep[8];
+    unpack8(*(const uint4*)(x + i * 8), f);
+    keep8(seed, i, thr, keep);
+    if (res) unpack8(*(const uint4*)(res + i * 8), r);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = keep[q] ? f[q] * scale : 0.f;
+      if (res) v += r[q];
+      f[q] = v;
+    }
+    *(uint4*)(y + i * 8) = pack8(f);
+  }
+}
+__global__ void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long long nch, uint32_t thr, float scale,
+                                   uint32_t seed) {
+  GSTRIDE(i, nch) {
+    bool keep[8];
+    keep8(seed, i, thr, keep);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[i * 8 + q] = keep[q] ? x[i * 8 + q] * scale : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int pp_dropout_bf16(const void* x, const void* res, void* y, long long n, float p, unsigned seed, pp_stream_t s) {
+  CHK8(n, "pp_dropout_bf16");
+  PP_CHECK_ARG(p >= 0.f && p < 1.f, "pp_dropout_bf16: p=%f", (double)p);
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)x, (const bfraw*)res, (bfraw*)y, n / 8,
+                     (uint32_t)(p * 65536.f + 0.5f), 1.f / (1.f - p), seed);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_dropout_f32(const float* x, float* y, long long n, float p, unsigned seed, pp_stream_t s) {
+  CHK8(n, "pp_dropout_f32");
+  PP_CHECK_ARG(p >= 0.f && p < 1.f, "pp_dropout_f32: p=%f", (double)p);
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, x, y, n / 8, (uint32_t)(p * 65536.f + 0.5f),
+                     1.f / (1.f - p), seed);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

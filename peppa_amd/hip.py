@@ -223,6 +223,14 @@ def add_bf16(a, b, out):
     call("pp_add_bf16", _p(a, bf16), _p(b, bf16), _p(out, bf16), a.numel(), _s())
 
 
+def dropout_bf16(x, y, p, seed, res=None):
+    call("pp_dropout_bf16", _p(x, bf16), _p(res, bf16), _p(y, bf16), x.numel(), float(p), int(seed) & 0xffffffff, _s())
+
+
+def dropout_f32(x, y, p, seed):
+    call("pp_dropout_f32", _p(x, f32), _p(y, f32), x.numel(), float(p), int(seed) & 0xffffffff, _s())
+
+
 def colsum_bf16(x, M, N, ld, out):
     call("pp_colsum_bf16", _p(x, bf16), M, N, ld, _p(out, f32), _s())
 

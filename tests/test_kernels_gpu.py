@@ -506,3 +506,27 @@ def test_maxpool_3x3s2_with_ties():
     torch.cuda.synchronize()
     assert torch.equal(y.float().cpu().reshape(N, Ho, Wo, C).permute(0, 3, 1, 2), y_ref.detach())
     close(dx.float().cpu().reshape(N, Hh, W, C).permute(0, 3, 1, 2), x.grad, rtol=1e-2, name="maxpool bwd")
+
+
+def test_dropout_mask_is_counter_based():
+    n, p = 1 << 20, 0.1
+    x = torch.ones(n, dtype=torch.bfloat16, device=DEV)
+    y1, y2, y3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    H.dropout_bf16(x, y1, p, 1234)
+    H.dropout_bf16(x, y2, p, 1234)
+    H.dropout_bf16(x, y3, p, 99)
+    g = torch.full((n,), 2.0, dtype=torch.float32, device=DEV)
+    gf = torch.empty_like(g)
+    H.dropout_f32(g, gf, p, 1234)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)           # same seed -> same mask
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.9) < 3e-3
+    kept = y1[y1 != 0].float()
+    assert (kept - 1 / 0.9).abs().max() < 1e-2                         # scaled by 1/(1-p) (bf16)
+    assert torch.equal(gf != 0, y1 != 0)                               # fp32 variant uses the same mask
+    r = torch.full((n,), 0.5, dtype=torch.bfloat16, device=DEV)
+    yr = torch.empty_like(x)
+    H.dropout_bf16(x, yr, p, 1234, res=r)
+    torch.cuda.synchronize()
+    assert torch.equal((yr.float() - 0.5) != 0, y1 != 0)
