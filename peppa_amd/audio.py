@@ -510,7 +510,7 @@ class Wav2Vec2Fn(torch.autograd.Function):
         model, grads = ctx.model, {}
         fe = model.feature_extractor
         dout = dout.contiguous().float()
-        with torch.no_grad():
+        with torch.no_grad(), L.ZeroPool("audio", dout.device):
             if ctx.full:
                 t = ctx.enc_tape
                 dfeat = _enc_backward(model.encoder, t, dout.view(t.M, -1), grads)

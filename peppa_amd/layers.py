@@ -21,7 +21,48 @@ def empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+class ZeroPool:
+    """One pre-zeroed fp32 arena per backward pass instead of hundreds of tiny fill kernels: the wgrad /
+    reduction outputs that must start at zero are carved out of it.  The size is learned on the first pass
+    (which falls back to torch.zeros) and the arena is a fresh allocation every pass, because the gradients
+    handed to autograd are views into it and stay alive until the next zero_grad."""
+    _sizes = {}
+    _active = []
+
+    def __init__(self, key, device):
+        self.key, self.device = (key, str(device)), device
+        self.buf, self.off, self.need = None, 0, 0
+
+    def __enter__(self):
+        n = ZeroPool._sizes.get(self.key, 0)
+        if n:
+            self.buf = torch.zeros(n, dtype=f32, device=self.device)
+        ZeroPool._active.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        ZeroPool._active.pop()
+        ZeroPool._sizes[self.key] = self.need
+        return False
+
+    def take(self, numel):
+        n = (numel + 63) // 64 * 64          # keep every slice 256-byte aligned
+        self.need += n
+        if self.buf is None or self.off + n > self.buf.numel():
+            return None
+        out = self.buf[self.off:self.off + numel]
+        self.off += n
+        return out
+
+
 def zeros(shape, dtype, like):
+    if dtype == f32 and ZeroPool._active and ZeroPool._active[-1].device == like.device:
+        numel = 1
+        for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+            numel *= d
+        t = ZeroPool._active[-1].take(numel)
+        if t is not None:
+            return t.view(shape)
     return torch.zeros(shape, dtype=dtype, device=like.device)
 
 

@@ -176,7 +176,8 @@ class VideoTrunkFn(torch.autograd.Function):
         with torch.no_grad():
             dz = torch.empty(B * Tn * HW, Cp, dtype=bf16, device=dout.device)
             H.spatial_mean_bwd(dout.contiguous().float(), dz, B, Tn, HW, 512, Cp)
-            V.trunk_backward(ctx.tape, dz, grads)
+            with L.ZeroPool("video", dout.device):
+                V.trunk_backward(ctx.tape, dz, grads)
         ctx.tape = None
         return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
 

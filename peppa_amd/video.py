@@ -260,8 +260,23 @@ def run_plan(plan, cur, thw, B, training, save, first=False):
     return cur, thw, tape
 
 
-def trunk_backward(tape, dz, grads):
-    """dz bf16 grad of the trunk output; fills `grads[param] = tensor`."""
+_WGRAD_STREAMS = {}
+
+
+def _wgrad_stream(device):
+    if device not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[device] = torch.cuda.Stream(device=device)
+    return _WGRAD_STREAMS[device]
+
+
+def trunk_backward(tape, dz, grads, overlap_wgrad=True):
+    """dz bf16 grad of the trunk output; fills `grads[param] = tensor`.
+
+    The weight gradient of a unit is off the critical chain (dz -> BN backward -> dy -> data gradient -> next
+    unit), so it is issued on a side stream: the MFMA/latency-bound wgrad kernels then overlap the HBM-bound
+    BatchNorm backward passes and the data-gradient GEMMs of the following units."""
+    main = torch.cuda.current_stream()
+    side = _wgrad_stream(dz.device) if overlap_wgrad else None
 
     def unit_bwd(rec, dz_in, relu, want_dres, dgrad_residual=None, need_dx=True):
         # units without a residual input recompute the ReLU mask from y (rec.has_res False -> z not read)
@@ -270,7 +285,14 @@ def trunk_backward(tape, dz, grads):
         if rec.bn.weight.requires_grad:
             grads[rec.bn.weight], grads[rec.bn.bias] = dg, db
         if rec.conv.weight.requires_grad:
-            grads[rec.conv.weight] = L.conv_wgrad(rec.x, dy, rec.geom, rec.conv.weight.shape)
+            if side is not None:
+                side.wait_stream(main)              # dy (and everything before it) is ready
+                with torch.cuda.stream(side):
+                    grads[rec.conv.weight] = L.conv_wgrad(rec.x, dy, rec.geom, rec.conv.weight.shape)
+                dy.record_stream(side)              # keep the allocator from recycling them under the side stream
+                rec.x.record_stream(side)
+            else:
+                grads[rec.conv.weight] = L.conv_wgrad(rec.x, dy, rec.geom, rec.conv.weight.shape)
         dx = None
         if need_dx and not rec.first:
             dx = L.conv_dgrad(dy, rec.geom, rec.wd, residual=dgrad_residual)
@@ -311,4 +333,6 @@ def trunk_backward(tape, dz, grads):
             i = j - 1
         else:
             i -= 1
+    if side is not None:
+        main.wait_stream(side)   # every weight gradient is complete before autograd hands them on
     return cur
