@@ -141,8 +141,13 @@ def main():
     if roof:
         flops, secs, n, name = roof
         ach = flops / secs / 1e12
+        traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/), when this family was profiled
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(name)
+        except Exception:
+            pass
         roof_obj = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                    "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4), "traffic": None, "kernel": name,
+                    "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4), "traffic": traffic, "kernel": name,
                     "launches": n, "avg_us": round(secs / n * 1e6, 1)}
     out = {
         "metric": "clip-pairs/sec (A+V encode + triplet loss), hparams_base", "value": round(value, 2),

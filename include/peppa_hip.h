@@ -23,6 +23,8 @@ enum pp_act { PP_ACT_NONE = 0, PP_ACT_GELU = 1, PP_ACT_RELU = 2 };
 enum pp_gather_mode { PP_DENSE = 0, PP_CONV_FWD = 1, PP_CONV_DGRAD = 2 };
 
 int pp_version(void);
+/* tuning switches (process-wide): "xcd_remap_igemm", "xcd_remap_wgrad" (0/1) */
+int pp_set_option(const char* name, int value);
 const char* pp_last_error(void);
 
 /* Row gather shared by pp_igemm / pp_wgrad: how logical row m and reduce index k of the

@@ -53,6 +53,7 @@ P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 SIGNATURES = {
     "pp_version": [],
     "pp_last_error": [],
+    "pp_set_option": [C.c_char_p, I],
     "pp_igemm": [C.POINTER(IGemmDesc), P],
     "pp_wgrad": [C.POINTER(WGradDesc), P],
     "pp_prep_conv_weight": [P, I, I, I, P, I, I, I, I, F, P],

@@ -13,6 +13,17 @@
 // tiles with 64-byte rows XOR-swizzled for conflict-free ds_read_b128, epilogue staged through
 // LDS so every global store is a full 16-byte row segment.
 #include "common.h"
+#include <string.h>
+
+int pp_opt_xcd_remap_igemm = 1;
+int pp_opt_xcd_remap_wgrad = 1;
+extern "C" int pp_set_option(const char* name, int value) {
+  if (!name) return PP_ERR_INVALID;
+  if (!strcmp(name, "xcd_remap_igemm")) { pp_opt_xcd_remap_igemm = value; return PP_OK; }
+  if (!strcmp(name, "xcd_remap_wgrad")) { pp_opt_xcd_remap_wgrad = value; return PP_OK; }
+  pp_set_error("pp_set_option: unknown option %s", name);
+  return PP_ERR_INVALID;
+}
 
 namespace {
 
@@ -38,7 +49,7 @@ struct RowInfo {
 
 template <int WN, int MODE, bool FULL, int NW>
 __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_igemm_desc p, const int nblk_n,
-                                                                       const RowDiv rd) {
+                                                                       const RowDiv rd, const int xcd_remap) {
   constexpr int BM = 32 * NW;      // rows per workgroup: one 32-row slab per wave
   constexpr int NT = 64 * NW;      // threads
   constexpr int RS = NT / 8;       // row stride between a thread's chunks (8 chunk columns per 128-byte row)
@@ -60,8 +71,14 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int nb = blockIdx.x % nblk_n;
-  const int mb = blockIdx.x / nblk_n;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (bid % 8 labels the XCD), so give
+  // each XCD a CONTIGUOUS range of tiles -- neighbouring M-tiles share their gather halo (rows m +/- W, +/- HW)
+  // and then hit the same private L2 instead of each XCD re-fetching it from HBM (bijective for any grid size)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int tile = xcd_remap ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3) : bid;
+  const int nb = tile % nblk_n;
+  const int mb = tile / nblk_n;
   const int z = blockIdx.z;
   const int zo = z / p.inner, zi = z % p.inner;
 
@@ -423,8 +440,8 @@ int launch_wn_nw(const pp_igemm_desc& d, hipStream_t s) {
   rd.dRt = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rt));
   const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
 #define PP_LAUNCH_IGEMM(MODE_)                                                                                       \
-  if (full) hipLaunchKernelGGL((igemm_kernel<WN, MODE_, true, NW>), grid, block, 0, s, d, nblk_n, rd);               \
-  else hipLaunchKernelGGL((igemm_kernel<WN, MODE_, false, NW>), grid, block, 0, s, d, nblk_n, rd)
+  if (full) hipLaunchKernelGGL((igemm_kernel<WN, MODE_, true, NW>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm); \
+  else hipLaunchKernelGGL((igemm_kernel<WN, MODE_, false, NW>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm)
   switch (d.g.mode) {
     case PP_DENSE: PP_LAUNCH_IGEMM(PP_DENSE); break;
     case PP_CONV_FWD: PP_LAUNCH_IGEMM(PP_CONV_FWD); break;

@@ -11,6 +11,7 @@
 #include "common.h"
 
 int pp_validate_gather(const pp_gather& g, int K, const char* who);
+extern int pp_opt_xcd_remap_wgrad;
 
 namespace {
 
@@ -42,7 +43,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int stride,
 template <int WI, int MODE, bool BIAS>
 __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_wgrad_desc p, const WGeom wg,
                                                                         const int nblk_i, const int nblk_j,
-                                                                        const int rows_per_split) {
+                                                                        const int rows_per_split, const int xcd_remap) {
   constexpr int TI = 16 * WI;
   constexpr int PS = (WI & 1) ? TI * 2 : TI * 2 + 32;  // P row stride (bytes), 32*odd
   constexpr int P_BYTES = MS * PS;
@@ -54,7 +55,14 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
   __shared__ int lut[128];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
+  // XCD-aware order (see igemm.hip): the (i, j) tiles of one M-split read the same dY / X rows, so keep
+  // consecutive tile indices on one XCD's L2
+  int bid;
+  {
+    const int nwg = gridDim.x, b0 = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = b0 & 7;
+    bid = xcd_remap ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b0 >> 3) : b0;
+  }
   const int ib = bid % nblk_i; bid /= nblk_i;
   const int jb = bid % nblk_j; bid /= nblk_j;
   const int split = bid;
@@ -280,10 +288,10 @@ int launch_wi(const pp_wgrad_desc& d, hipStream_t s) {
   const long long gx = (long long)nblk_i * nblk_j * msplit;
   dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(256);
   if (d.g.mode == PP_DENSE) {
-    if (d.dbias) hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, true>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split);
-    else hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split);
+    if (d.dbias) hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, true>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+    else hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
   } else {
-    hipLaunchKernelGGL((wgrad_kernel<WI, PP_CONV_FWD, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split);
+    hipLaunchKernelGGL((wgrad_kernel<WI, PP_CONV_FWD, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
   }
   PP_LAUNCH_CHECK();
   return PP_OK;

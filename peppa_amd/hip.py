@@ -28,6 +28,10 @@ def _p(t, dtype=None):
     return C.c_void_p(t.data_ptr())
 
 
+def set_option(name, value):
+    call("pp_set_option", name.encode(), int(value))
+
+
 def rup(x, m):
     return (x + m - 1) // m * m
 

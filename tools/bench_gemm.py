@@ -9,6 +9,9 @@ dev = "cuda"
 B = int(os.environ.get("B", "64"))
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 case_filter = os.environ.get("CASE", "")
+for opt in ("xcd_remap_igemm", "xcd_remap_wgrad"):
+    if opt.upper() in os.environ:
+        H.set_option(opt, int(os.environ[opt.upper()]))
 
 
 def timeit(fn, n=10):
