@@ -84,7 +84,7 @@ def main():
     import pig.models
     from peppa_amd import hip as H
     from peppa_amd.data import synthetic_batch
-    from peppa_amd.dist import GradBuckets
+    from peppa_amd.dist import default_buckets
     cfg = yaml.safe_load(open(args.config))
     cfg["video"]["pretrained"] = False   # weights cannot be downloaded offline: random init, same architecture
     cfg["audio"]["pretrained"] = False
@@ -94,9 +94,7 @@ def main():
     batch = synthetic_batch(args.batch, args.frames, args.size, args.samples, seed=1234 + rank).to(dev)
     buckets = None
     if world > 1:
-        audio = list(net.audio_encoder.parameters())
-        video = [p for n, p in net.video_encoder.named_parameters() if not n.startswith("video.fc")]
-        buckets = GradBuckets([("audio", audio), ("video", video)], dev)
+        buckets = default_buckets(net, dev)
 
     def step(i):
         optim.zero_grad(set_to_none=True)

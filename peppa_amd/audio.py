@@ -11,7 +11,7 @@ epilogues, LayerNorm, batched attention) driven by `Wav2Vec2Fn`.
 
 Dropout / LayerDrop follow the modules' `p` / `layer_drop` in train mode (torchaudio defaults 0.1): masks
 come from a counter-based hash (seed, element index) and are regenerated in the backward pass; LayerDrop
-uses the host RNG like torchaudio (`torch.rand(1).item() <= layer_drop`).  Parity tests set p = 0.
+uses a host RNG like torchaudio (`torch.rand(1).item() <= layer_drop`), seeded identically on every rank.  Parity tests set p = 0.
 """
 import torch
 from torch import nn
@@ -109,6 +109,9 @@ class Transformer(nn.Module):
         self.layer_drop = layer_drop
         self.dropout = nn.Dropout(p)
         self.layers = nn.ModuleList([EncoderLayer(dim, heads, inner, p) for _ in range(n_layers)])
+        # LayerDrop decisions come from a dedicated host generator with a fixed seed, so that all data-parallel
+        # ranks drop the same layers (a parameter then has a gradient on every rank or on none)
+        self._ld_gen = torch.Generator().manual_seed(0x5EED)
 
 
 class Encoder(nn.Module):
@@ -342,7 +345,7 @@ def _enc_forward(enc, feat, B, T, save, training=False):
         H.dropout_bf16(x, x, *t.d_tr)
     t.layers = []
     for layer in tr.layers:
-        if training and tr.layer_drop > 0 and torch.rand(1).item() <= tr.layer_drop:
+        if training and tr.layer_drop > 0 and torch.rand(1, generator=tr._ld_gen).item() <= tr.layer_drop:
             continue   # LayerDrop: the layer is skipped for this step (host RNG, like torchaudio)
         r = _Rec()
         att, ff = layer.attention, layer.feed_forward

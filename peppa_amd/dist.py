@@ -94,14 +94,16 @@ class GradBuckets:
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):
-        """Wait for the collectives and point every p.grad at its reduced bucket view."""
+        """Wait for the collectives and point every p.grad at its reduced bucket view.  Parameters that got no
+        gradient this step (unused, or a layer skipped by LayerDrop on every rank -- the decision is shared)
+        contribute zeros to the sum and keep p.grad = None, so the optimizer skips them like the reference."""
         for b in self.buckets:
-            if b["pending"] > 0:  # parameters that received no gradient this step (unused / frozen path)
-                missing = [p for p in b["params"] if p.grad is None]
-                if len(missing) != b["pending"]:
+            b["had_grad"] = [p.grad is not None for p in b["params"]]
+            if b["pending"] == len(b["params"]):
+                continue   # nothing arrived (e.g. a layer dropped by LayerDrop on every rank): no collective
+            if b["pending"] > 0:
+                if sum(not h for h in b["had_grad"]) != b["pending"]:
                     raise RuntimeError(f"bucket {b['name']}: inconsistent gradient arrival")
-                for p in missing:
-                    self._by_param[p]  # keep mapping; contribute zeros
                 for p, v in zip(b["params"], b["views"]):
                     if p.grad is None:
                         v.zero_()
@@ -114,6 +116,29 @@ class GradBuckets:
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
         for b in self.buckets:
-            for p, v in zip(b["params"], b["views"]):
-                p.grad = v
+            for p, v, had in zip(b["params"], b["views"], b["had_grad"]):
+                if had:
+                    p.grad = v
         self.reset()
+
+
+def default_buckets(net, device):
+    """Bucket layout for PeppaPig: the video tower, the wav2vec2 feature extractor, one bucket per transformer
+    layer (so LayerDrop leaves whole buckets empty instead of forcing a late, unoverlapped reduce) and the rest of
+    the audio tower.  24-130 MB each: large enough for RCCL's multi-ring bandwidth over the 7 xGMI links."""
+    audio = net.audio_encoder
+    groups = []
+    enc = getattr(audio.audio, "encoder", None)
+    layer_params = set()
+    if enc is not None:
+        for i, layer in enumerate(enc.transformer.layers):
+            ps = list(layer.parameters())
+            layer_params.update(ps)
+            groups.append((f"audio.layer{i}", ps))
+    fe = list(audio.audio.feature_extractor.parameters())
+    groups.append(("audio.feature_extractor", fe))
+    seen = layer_params | set(fe)
+    groups.append(("audio.rest", [p for p in audio.parameters() if p not in seen]))
+    vname = "image.fc" if hasattr(net.video_encoder, "image") else "video.fc"
+    groups.append(("video", [p for n, p in net.video_encoder.named_parameters() if not n.startswith(vname)]))
+    return GradBuckets([(n, ps) for n, ps in groups if any(p.requires_grad for p in ps)], device)

@@ -7,7 +7,7 @@ import time
 import logging
 import torch
 
-from .dist import GradBuckets, is_dist
+from .dist import default_buckets, is_dist
 
 log = logging.getLogger(__name__)
 
@@ -38,10 +38,7 @@ class Trainer:
         optim = net.configure_optimizers()
         buckets = None
         if is_dist():
-            dev = next(net.parameters()).device
-            audio = list(net.audio_encoder.parameters())
-            video = [p for n, p in net.video_encoder.named_parameters() if not n.startswith("video.fc")]
-            buckets = GradBuckets([("audio", audio), ("video", video)], dev)
+            buckets = default_buckets(net, next(net.parameters()).device)
         net.train()
         t0 = time.time()
         optim.zero_grad(set_to_none=True)

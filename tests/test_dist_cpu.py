@@ -61,3 +61,31 @@ def test_single_process_is_identity():
     assert not is_dist()
     V2, A2 = gather_embeddings(V, A)
     assert V2 is V and A2 is A
+
+
+def test_default_buckets_cover_every_trainable_parameter_once():
+    import copy
+    import warnings
+    warnings.filterwarnings("ignore")
+    import pig.models
+    from pig.execution import default_config
+    from peppa_amd.dist import default_buckets
+    cfg = copy.deepcopy(default_config)
+    cfg["video"]["pretrained"] = cfg["audio"]["pretrained"] = False
+    cfg["audio"]["freeze_feature_extractor"] = True
+    net = pig.models.PeppaPig(cfg)
+    gb = default_buckets(net, "cpu")
+    in_buckets = [p for b in gb.buckets for p in b["params"]]
+    assert len(in_buckets) == len(set(in_buckets))
+    want = {p for n, p in net.named_parameters() if p.requires_grad and "video.fc" not in n}
+    assert set(in_buckets) == want
+    names = [b["name"] for b in gb.buckets]
+    assert "audio.layer11" in names and "video" in names and "audio.feature_extractor" not in names
+    # a bucket whose parameters got no gradient at all is skipped; a complete one is reduced (no-op on 1 process)
+    layer0 = next(b for b in gb.buckets if b["name"] == "audio.layer0")
+    for p in layer0["params"]:
+        p.grad = torch.ones_like(p)
+        gb._on_grad(p)
+    gb.finish()
+    assert all(p.grad is not None for p in layer0["params"])
+    assert all(p.grad is None for b in gb.buckets if b["name"] == "audio.layer1" for p in b["params"])
