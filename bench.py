@@ -77,7 +77,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PEPPA_FORCE_DIST") == "1"
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import yaml
@@ -93,7 +99,7 @@ def main():
     optim = net.configure_optimizers()
     batch = synthetic_batch(args.batch, args.frames, args.size, args.samples, seed=1234 + rank).to(dev)
     buckets = None
-    if world > 1:
+    if use_dist:
         buckets = default_buckets(net, dev)
 
     def step(i):
@@ -111,25 +117,24 @@ def main():
     H.PROFILE_STREAM = torch.cuda.current_stream()   # the video trunk's stream; the audio tower overlaps on a side stream
     H.PROFILE_ON = True
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     H.PROFILE_ON = False
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     ms = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
@@ -159,7 +164,7 @@ def main():
                    "loss": round(float(loss.item()), 5)},
         "roofline": roof_obj,
     }
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if not args.no_cpu_baseline and world == 1:
         try:

@@ -12,12 +12,17 @@ One process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI) or "g
     only covers the local clips ("all-gather gradient routing").
 BatchNorm uses per-rank statistics (documented deviation from a single-process N=512 batch).
 """
+import os
 import torch
 import torch.distributed as dist
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True under torch.distributed with more than one rank (PEPPA_FORCE_DIST=1 also exercises the collective
+    path with a single rank, which is how the RCCL plumbing is smoke-tested on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("PEPPA_FORCE_DIST") == "1"
 
 
 class _GatherFn(torch.autograd.Function):
@@ -75,6 +80,8 @@ class GradBuckets:
             b["work"] = None
 
     def _on_grad(self, p):
+        if p.grad is None:   # autograd also runs the hook when a Function returned None for this parameter
+            return           # (e.g. a layer skipped by LayerDrop): nothing arrived
         b = self._by_param[p]
         b["pending"] -= 1
         if b["pending"] == 0:

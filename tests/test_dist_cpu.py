@@ -83,6 +83,10 @@ def test_default_buckets_cover_every_trainable_parameter_once():
     assert "audio.layer11" in names and "video" in names and "audio.feature_extractor" not in names
     # a bucket whose parameters got no gradient at all is skipped; a complete one is reduced (no-op on 1 process)
     layer0 = next(b for b in gb.buckets if b["name"] == "audio.layer0")
+    layer1 = next(b for b in gb.buckets if b["name"] == "audio.layer1")
+    for p in layer1["params"]:      # autograd also fires the hook when a Function returned None (LayerDrop)
+        gb._on_grad(p)
+    assert layer1["pending"] == len(layer1["params"])
     for p in layer0["params"]:
         p.grad = torch.ones_like(p)
         gb._on_grad(p)
