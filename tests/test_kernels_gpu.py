@@ -530,3 +530,50 @@ def test_dropout_mask_is_counter_based():
     H.dropout_bf16(x, yr, p, 1234, res=r)
     torch.cuda.synchronize()
     assert torch.equal((yr.float() - 0.5) != 0, y1 != 0)
+
+
+def test_batchnorm_bwd_mask_recomputed_from_y():
+    """Units without a residual input pass z=None: the ReLU mask comes from y*scale+shift."""
+    g = torch.Generator().manual_seed(21)
+    B, C, T, Hh, W = 2, 144, 2, 6, 5
+    y = rb(torch.randn(B, C, T, Hh, W, generator=g) * 1.5).requires_grad_()
+    bn = torch.nn.BatchNorm3d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    z_ref = F.relu(bn(y))
+    dz = rb(torch.randn(z_ref.shape, generator=g))
+    z_ref.backward(dz)
+    P = _BNP()
+    P.weight, P.bias = bn.weight.detach().clone().to(DEV), bn.bias.detach().clone().to(DEV)
+    P.running_mean, P.running_var = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    yc = to_cl(y.detach(), C)
+    M = yc.shape[0]
+    partials = torch.empty(2, 2, C, device=DEV)
+    H.colstats_bf16(yc, M, C, partials, 2)
+    z, sv = L.bn_fwd(yc, partials, 2, M, P, relu=True)
+    dy1, _, dg1, db1 = L.bn_bwd(to_cl(dz, C), yc, z, sv, P.weight, relu=True)
+    dy2, _, dg2, db2 = L.bn_bwd(to_cl(dz, C), yc, None, sv, P.weight, relu=True)
+    torch.cuda.synchronize()
+    thw = (T, Hh, W)
+    close(from_cl(dy2, B, thw, C), y.grad, name="bn dx (mask from y)")
+    close(dg2, bn.weight.grad, name="bn dgamma (mask from y)")
+    assert (dy1.float() - dy2.float()).abs().max().item() <= 2e-2 * y.grad.abs().max().item()
+    assert (db1 - db2).abs().max().item() <= 1e-2 * bn.bias.grad.abs().max().item() + 1e-3
+
+
+def test_strided_dgrad_with_residual_accumulate():
+    """Parity-class decomposition + output row map + residual epilogue (first conv of layer2-4)."""
+    g = torch.Generator().manual_seed(33)
+    Ci, Co, k, s, p, B, T, Hh, W = 64, 96, (1, 3, 3), (1, 2, 2), (0, 1, 1), 2, 2, 9, 11
+    x = rb(torch.randn(B, Ci, T, Hh, W, generator=g)).requires_grad_()
+    w = rb(torch.randn(Co, Ci, *k, generator=g) / 24)
+    y_ref = F.conv3d(x, w, stride=s, padding=p)
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    res = rb(torch.randn(B, Ci, T, Hh, W, generator=g))
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    _, wd = L.prep_conv_weights(w.to(DEV), geom)
+    dx = L.conv_dgrad(to_cl(dy, geom.out_cstride), geom, wd, residual=to_cl(res, geom.in_cstride))
+    torch.cuda.synchronize()
+    close(from_cl(dx, B, (T, Hh, W), Ci), x.grad + res, name="strided dgrad + residual")
