@@ -16,10 +16,12 @@
 #include <string.h>
 
 int pp_opt_xcd_remap_igemm = 1;
+int pp_opt_persistent = 1;
 int pp_opt_xcd_remap_wgrad = 1;
 extern "C" int pp_set_option(const char* name, int value) {
   if (!name) return PP_ERR_INVALID;
   if (!strcmp(name, "xcd_remap_igemm")) { pp_opt_xcd_remap_igemm = value; return PP_OK; }
+  if (!strcmp(name, "persistent_igemm")) { pp_opt_persistent = value; return PP_OK; }
   if (!strcmp(name, "xcd_remap_wgrad")) { pp_opt_xcd_remap_wgrad = value; return PP_OK; }
   pp_set_error("pp_set_option: unknown option %s", name);
   return PP_ERR_INVALID;
@@ -49,7 +51,7 @@ struct RowInfo {
 
 template <int WN, int MODE, bool FULL, int NW>
 __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_igemm_desc p, const int nblk_n,
-                                                                       const RowDiv rd, const int xcd_remap) {
+                                                                       const RowDiv rd, const int xcd_remap, const int ntiles) {
   constexpr int BM = 32 * NW;      // rows per workgroup: one 32-row slab per wave
   constexpr int NT = 64 * NW;      // threads
   constexpr int RS = NT / 8;       // row stride between a thread's chunks (8 chunk columns per 128-byte row)
@@ -71,14 +73,22 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (bid % 8 labels the XCD), so give
-  // each XCD a CONTIGUOUS range of tiles -- neighbouring M-tiles share their gather halo (rows m +/- W, +/- HW)
-  // and then hit the same private L2 instead of each XCD re-fetching it from HBM (bijective for any grid size)
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-  const int tile = xcd_remap ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3) : bid;
-  const int nb = tile % nblk_n;
-  const int mb = tile / nblk_n;
+  // Persistent workgroups: block b walks tiles b, b + G, b + 2G, ... (G = gridDim.x), prefetching the first K-step of
+  // its next tile under the epilogue of the current one, so the cold-start load latency and the prologue are paid
+  // once per workgroup instead of once per tile.
+  // XCD-aware order inside each wave of G tiles: workgroups are dealt round-robin over the 8 XCDs (bid % 8 labels
+  // the XCD), so each XCD gets a CONTIGUOUS tile range -- neighbouring M-tiles share their gather halo (rows
+  // m +/- W, +/- HW) and hit the same private L2 instead of every XCD re-fetching it (bijective for any G).
+  const int G = gridDim.x, bid = blockIdx.x;
+  auto tile_index = [&](int it) __attribute__((always_inline)) -> int {
+    const int base = it * G;
+    const int cnt = ntiles - base < G ? ntiles - base : G;
+    if (bid >= cnt) return -1;
+    const int xq = cnt >> 3, xr = cnt & 7, xcd = bid & 7;
+    const int t = (xcd_remap && cnt >= 8) ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3) : bid;
+    return base + t;
+  };
+  int mb = 0, nb = 0;
   const int z = blockIdx.z;
   const int zo = z / p.inner, zi = z % p.inner;
 
@@ -113,53 +123,57 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
   const bool unit_stride = (g.st == 1 && g.sh == 1 && g.sw == 1);
   const int sft = g.st == 2, sfh = g.sh == 2, sfw = g.sw == 2;
 
-  // ---- per-thread bookkeeping: 4 A rows (tid>>3 + 32 i) and NBI B rows, one 16-byte chunk column kq ----
+  // ---- per-thread bookkeeping: 4 A rows (tid>>3 + RS i) and NBI B rows, one 16-byte chunk column kq ----
   const int kq = tid & 7;
   RowInfo ri[NAI];
-#pragma unroll
-  for (int i = 0; i < NAI; ++i) {
-    const int m = mb * BM + (tid >> 3) + RS * i;
-    const bool valid = m < p.M;
-    const int mm = valid ? m : 0;
-    ri[i].nbase = 0;
-    if (MODE == PP_DENSE) {
-      ri[i].base = valid ? (unsigned)(mm * g.lda) * 2u : OOB;
-      ri[i].bt = ri[i].bh = ri[i].bw = 0;
-    } else {
-      const uint32_t t1 = fdiv((uint32_t)mm, rd.dRw);
-      const int rw = mm - (int)t1 * g.Rw;
-      const uint32_t t2 = fdiv(t1, rd.dRh);
-      const int rh = (int)t1 - (int)t2 * g.Rh;
-      const int n = (int)fdiv(t2, rd.dRt);
-      const int rt = (int)t2 - n * g.Rt;
-      ri[i].nbase = n * g.Gt * g.Gh * g.Gw;
-      if (MODE == PP_CONV_FWD) {
-        ri[i].bt = rt * g.st - g.pt;
-        ri[i].bh = rh * g.sh - g.ph;
-        ri[i].bw = rw * g.sw - g.pw;
-      } else {
-        ri[i].bt = rt + g.pt;
-        ri[i].bh = rh + g.ph;
-        ri[i].bw = rw + g.pw;
-      }
-      ri[i].base = (unsigned)((ri[i].nbase + (ri[i].bt * g.Gh + ri[i].bh) * g.Gw + ri[i].bw) * g.cstride) * 2u;
-      if (!valid) ri[i].bt = -(1 << 20);
-    }
-  }
   unsigned bbase[NBI];
-#pragma unroll
-  for (int i = 0; i < NBI; ++i) {
-    const int brow = (tid >> 3) + RS * i;
-    const int n = nb * BN + brow;
-    bbase[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : OOB;
-  }
-
-  int kcur = kq * 8;            // this thread's k within the current K-step
+  int kcur = 0;                 // this thread's k within the current K-step
   int tap = 0, cch = 0;         // conv modes: k = tap*cg + cch
-  if (MODE != PP_DENSE) {
-    tap = kcur / g.cg;
-    cch = kcur % g.cg;
-  }
+  auto setup_tile = [&](int tile) __attribute__((always_inline)) {
+    nb = tile % nblk_n;
+    mb = tile / nblk_n;
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+      const int m = mb * BM + (tid >> 3) + RS * i;
+      const bool valid = m < p.M;
+      const int mm = valid ? m : 0;
+      ri[i].nbase = 0;
+      if (MODE == PP_DENSE) {
+        ri[i].base = valid ? (unsigned)(mm * g.lda) * 2u : OOB;
+        ri[i].bt = ri[i].bh = ri[i].bw = 0;
+      } else {
+        const uint32_t t1 = fdiv((uint32_t)mm, rd.dRw);
+        const int rw = mm - (int)t1 * g.Rw;
+        const uint32_t t2 = fdiv(t1, rd.dRh);
+        const int rh = (int)t1 - (int)t2 * g.Rh;
+        const int n = (int)fdiv(t2, rd.dRt);
+        const int rt = (int)t2 - n * g.Rt;
+        ri[i].nbase = n * g.Gt * g.Gh * g.Gw;
+        if (MODE == PP_CONV_FWD) {
+          ri[i].bt = rt * g.st - g.pt;
+          ri[i].bh = rh * g.sh - g.ph;
+          ri[i].bw = rw * g.sw - g.pw;
+        } else {
+          ri[i].bt = rt + g.pt;
+          ri[i].bh = rh + g.ph;
+          ri[i].bw = rw + g.pw;
+        }
+        ri[i].base = (unsigned)((ri[i].nbase + (ri[i].bt * g.Gh + ri[i].bh) * g.Gw + ri[i].bw) * g.cstride) * 2u;
+        if (!valid) ri[i].bt = -(1 << 20);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+      const int brow = (tid >> 3) + RS * i;
+      const int n = nb * BN + brow;
+      bbase[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : OOB;
+    }
+    kcur = kq * 8;
+    if (MODE != PP_DENSE) {
+      tap = kcur / g.cg;
+      cch = kcur % g.cg;
+    }
+  };
 
   u32x4 ra[NAI], rb[NBI];
   auto load_stage = [&]() __attribute__((always_inline)) {
@@ -224,10 +238,6 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
   };
 
   f32x4 acc[2][WN];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
   auto compute = [&](const unsigned char* buf) __attribute__((always_inline)) {
@@ -246,30 +256,16 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
     }
   };
 
-  // ---- main loop: the next K-step's global loads (one register stage) fly under this step's MFMAs;
-  // two LDS buffers, one barrier per 64-deep K-step
-  const int nk = (p.K + BK - 1) / BK;
-  load_stage();
-  store_stage(smem);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {   // single loop body + runtime buffer toggle: half the registers of a 2x unroll
-    const bool more = kt + 1 < nk;
-    if (more) load_stage();
-    compute(smem + cur * LOOP_BYTES);
-    cur ^= 1;
-    if (more) store_stage(smem + cur * LOOP_BYTES);
-    __syncthreads();
-  }
-
-  // ---- epilogue -----------------------------------------------------------------------------
+  // ---- epilogue of one finished tile (mb_e, nb_e); defined below the tile loop's helpers -------------------
+  const int ncols_store = (p.N + 7) & ~7;
+  auto epilogue = [&](const int mb_e, const int nb_e) __attribute__((always_inline)) {
   // FULL = bias / activation / residual / pre-activation copy; otherwise plain store (+ optional
   // BatchNorm column statistics).  Flags are tested once, outside the per-value loops.
-  const int m_wave = mb * BM + wave * 32;
+  const int m_wave = mb_e * BM + wave * 32;
   if (FULL && bias) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      const int n = nb * BN + j * 16 + fr;
+      const int n = nb_e * BN + j * 16 + fr;
       const float bv = n < p.N ? bias[n] : 0.f;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -301,7 +297,7 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        const int n = nb * BN + j * 16 + fr;
+        const int n = nb_e * BN + j * 16 + fr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m_wave + mt * 16 + fq * 4 + r;
@@ -315,7 +311,6 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
   // The slab is wave-private, so LDS program order (+ lgkmcnt waits) is the only synchronisation needed.
   unsigned char* stg = smem + wave * 16 * STG_STRIDE;
   unsigned char* stg_w = stg + (fq * 4) * STG_STRIDE + fr * 2;
-  const int ncols_store = (p.N + 7) & ~7;
   auto write_out = [&](bfraw* Cout, const bfraw* residual) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -331,7 +326,7 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
         const int row = cid / (2 * WN);
         const int ch = cid % (2 * WN);
         const int m = m_wave + mt * 16 + row;
-        const int col = nb * BN + ch * 8;
+        const int col = nb_e * BN + ch * 8;
         if (cid < 32 * WN && m < p.M && col < ncols_store) {
           uint4 v = *(const uint4*)(stg + row * STG_STRIDE + ch * 16);
           long long orow = m;
@@ -395,8 +390,8 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
     // partial rows are always per 128 output rows (independent of the workgroup height)
     for (int idx = tid; idx < BN * (NW / 4); idx += NT) {
       const int c = idx % BN, h = idx / BN;
-      const int n = nb * BN + c;
-      const long long prow = (long long)mb * (NW / 4) + h;
+      const int n = nb_e * BN + c;
+      const long long prow = (long long)mb_e * (NW / 4) + h;
       if (n < p.ldstat && prow * 128 < p.M) {
         float a = 0.f, b = 0.f;
 #pragma unroll
@@ -408,6 +403,44 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
         p.colstats[(prow * 2 + 1) * p.ldstat + n] = b;
       }
     }
+  }
+  };
+
+  // ---- tile loop: one register stage of global loads flies under the MFMAs of the current K-step; two LDS buffers,
+  // one barrier per 64-deep K-step; the next tile's first stage is issued before the epilogue
+  const int nk = (p.K + BK - 1) / BK;
+  int it = 0;
+  const int first = tile_index(0);
+  if (first < 0) return;
+  setup_tile(first);
+  load_stage();
+  while (true) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    store_stage(smem);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {   // single loop body + runtime buffer toggle: half the registers of a 2x unroll
+      const bool more = kt + 1 < nk;
+      if (more) load_stage();
+      compute(smem + cur * LOOP_BYTES);
+      cur ^= 1;
+      if (more) store_stage(smem + cur * LOOP_BYTES);
+      __syncthreads();
+    }
+    const int mb_done = mb, nb_done = nb;
+    const int next = tile_index(++it);
+    // plain-store epilogues are light on registers: the cold loads of the next tile fly under them.  The fused
+    // (bias / residual / statistics) epilogues need the registers themselves, so there the loads are issued after.
+    if (!FULL && next >= 0) {
+      setup_tile(next);
+      load_stage();
+    }
+    epilogue(mb_done, nb_done);
+    if (FULL || next < 0) break;   // fused epilogues run one tile per workgroup (the launcher sizes the grid so)
+    __syncthreads();   // the staging slabs of the epilogue alias the loop buffers
   }
 }
 
@@ -430,18 +463,23 @@ int launch_wn_nw(const pp_igemm_desc& d, hipStream_t s) {
   constexpr int BM = 32 * NW;
   const int nblk_n = (d.N + 16 * WN - 1) / (16 * WN);
   const long long nblk_m = ((long long)d.M + BM - 1) / BM;
-  const long long gx = nblk_m * nblk_n;
-  if (gx <= 0 || gx > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
+  const long long ntiles = nblk_m * nblk_n;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
+  // persistent grid: as many workgroups as stay resident (LDS-limited: 3 / 2 / 1 per CU) once there are >= 4 waves of
+  // tiles, otherwise one tile per workgroup
+  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
+  const long long resident = 256LL * (WN <= 4 ? 3 : (WN <= 9 ? 2 : 1));
+  long long gx = ntiles;
+  if (pp_opt_persistent && !full && d.nbatch == 1 && ntiles >= 4 * resident) gx = resident;
   dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(64 * NW);
   RowDiv rd;
   const bool dense = d.g.mode == PP_DENSE;
   rd.dRw = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rw));
   rd.dRh = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rh));
   rd.dRt = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rt));
-  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
 #define PP_LAUNCH_IGEMM(MODE_)                                                                                       \
-  if (full) hipLaunchKernelGGL((igemm_kernel<WN, MODE_, true, NW>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm); \
-  else hipLaunchKernelGGL((igemm_kernel<WN, MODE_, false, NW>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm)
+  if (full) hipLaunchKernelGGL((igemm_kernel<WN, MODE_, true, NW>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles); \
+  else hipLaunchKernelGGL((igemm_kernel<WN, MODE_, false, NW>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles)
   switch (d.g.mode) {
     case PP_DENSE: PP_LAUNCH_IGEMM(PP_DENSE); break;
     case PP_CONV_FWD: PP_LAUNCH_IGEMM(PP_CONV_FWD); break;
