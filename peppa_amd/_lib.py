@@ -124,6 +124,11 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = _RESTYPE.get(name, C.c_int)
         _lib = h
+        # tuning switches for A/B measurements: PEPPA_HIP_OPTIONS="ring_igemm=0,xcd_remap_wgrad=0"
+        for item in filter(None, os.environ.get("PEPPA_HIP_OPTIONS", "").split(",")):
+            key, _, val = item.partition("=")
+            if h.pp_set_option(key.strip().encode(), int(val)) != 0:
+                raise PeppaHipError(f"PEPPA_HIP_OPTIONS: {h.pp_last_error().decode()}")
     return _lib
 
 

@@ -17,10 +17,12 @@
 
 int pp_opt_xcd_remap_igemm = 1;
 int pp_opt_persistent = 1;
+int pp_opt_ring = 192; // LDS-DMA ring variant once there are this many 256-row tiles (0 = never)
 int pp_opt_xcd_remap_wgrad = 1;
 extern "C" int pp_set_option(const char* name, int value) {
   if (!name) return PP_ERR_INVALID;
   if (!strcmp(name, "xcd_remap_igemm")) { pp_opt_xcd_remap_igemm = value; return PP_OK; }
+  if (!strcmp(name, "ring_igemm")) { pp_opt_ring = value; return PP_OK; }
   if (!strcmp(name, "persistent_igemm")) { pp_opt_persistent = value; return PP_OK; }
   if (!strcmp(name, "xcd_remap_wgrad")) { pp_opt_xcd_remap_wgrad = value; return PP_OK; }
   pp_set_error("pp_set_option: unknown option %s", name);
@@ -49,9 +51,28 @@ struct RowInfo {
   int nbase;         // strided data-gradient only: n * Gt*Gh*Gw
 };
 
-template <int WN, int MODE, bool FULL, int NW>
-__global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const pp_igemm_desc p, const int nblk_n,
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) buffer_rsrc;
+
+// LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform dst + 16 * lane; a lane whose offset is out of range
+// writes zeros.  (Kept out of the kernel template: inside it the host pass silently drops the kernel's stub.)
+__device__ __forceinline__ void lds_dma16(const buffer_rsrc rs, unsigned char* dst, const unsigned off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, off, 0, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// RING = false: register-staged loads, two LDS buffers, 2-3 workgroups per CU hide each other's latencies.
+// RING = true : 256-row tiles (8 waves), one workgroup per CU; operands go global -> LDS by LDS-DMA
+//               (buffer_load ... lds) into a three-slot ring with two K-steps in flight across raw barriers and
+//               counted vmcnt waits.  The swizzled LDS image is the same: the XOR moves to the source address.
+template <int WN, int MODE, bool FULL, int NW, bool RING>
+__global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm_kernel(const pp_igemm_desc p, const int nblk_n,
                                                                        const RowDiv rd, const int xcd_remap, const int ntiles) {
+  static_assert(!RING || (NW == 8 && WN <= 9), "ring variant: 8 waves, BN <= 144");
   constexpr int BM = 32 * NW;      // rows per workgroup: one 32-row slab per wave
   constexpr int NT = 64 * NW;      // threads
   constexpr int RS = NT / 8;       // row stride between a thread's chunks (8 chunk columns per 128-byte row)
@@ -63,12 +84,15 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
   constexpr int STAT_BYTES = NW * BN * 2 * 4;
   constexpr int LOOP_BYTES = A_BYTES + B_BYTES;
   constexpr int EPI_BYTES = STG_BYTES + STAT_BYTES;
-  constexpr int SMEM = 2 * LOOP_BYTES > EPI_BYTES ? 2 * LOOP_BYTES : EPI_BYTES;
+  constexpr int NSLOT = RING ? 3 : 2;
+  constexpr int SMEM = NSLOT * LOOP_BYTES > EPI_BYTES ? NSLOT * LOOP_BYTES : EPI_BYTES;
+  static_assert(!RING || EPI_BYTES <= LOOP_BYTES, "the epilogue staging must fit one ring slot");
   constexpr int NAI = 4;                       // A chunks per thread and K-step
   constexpr int NBI = (BN * 8 + NT - 1) / NT;  // B chunks per thread and K-step
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-  __shared__ int lut[128];      // packed (dt, dh, dw) per tap
-  __shared__ int lut_off[128];  // byte offset of the tap inside the source tensor (linear part)
+  // one LDS object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM + (MODE != PP_DENSE ? 1024 : 0)];
+  int* const lut = (int*)(smem + SMEM);            // packed (dt, dh, dw) per tap
+  int* const lut_off = (int*)(smem + SMEM + 512);  // byte offset of the tap inside the source tensor (linear part)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -124,7 +148,9 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
   const int sft = g.st == 2, sfh = g.sh == 2, sfw = g.sw == 2;
 
   // ---- per-thread bookkeeping: 4 A rows (tid>>3 + RS i) and NBI B rows, one 16-byte chunk column kq ----
-  const int kq = tid & 7;
+  // register staging: thread loads chunk kq and stores it at slot kq ^ swz(row); LDS-DMA lands lane-linear, so the
+  // thread owning slot (tid & 7) fetches chunk (tid & 7) ^ swz(row) instead (swz(row) is the same for all its rows)
+  const int kq = RING ? ((tid & 7) ^ swz(tid >> 3)) : (tid & 7);
   RowInfo ri[NAI];
   unsigned bbase[NBI];
   int kcur = 0;                 // this thread's k within the current K-step
@@ -175,15 +201,13 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
     }
   };
 
-  u32x4 ra[NAI], rb[NBI];
-  auto load_stage = [&]() __attribute__((always_inline)) {
+  u32x4 ra[RING ? 1 : NAI], rb[RING ? 1 : NBI];
+  // byte offsets of this thread's chunks for the next K-step (OOB where the gather leaves the tensor), then advance
+  auto stage_offsets = [&](unsigned (&offA)[NAI], unsigned (&offB)[NBI]) __attribute__((always_inline)) {
     const bool k_ok = kcur < p.K;
     if (MODE == PP_DENSE) {
 #pragma unroll
-      for (int i = 0; i < NAI; ++i) {
-        const unsigned off = (k_ok && ri[i].base != OOB) ? ri[i].base + (unsigned)kcur * 2u : OOB;
-        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
-      }
+      for (int i = 0; i < NAI; ++i) offA[i] = (k_ok && ri[i].base != OOB) ? ri[i].base + (unsigned)kcur * 2u : OOB;
     } else {
       const bool tap_ok = tap < ntaps;
       const int e = lut[tap & 127];
@@ -210,21 +234,52 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
             off = (unsigned)((r.nbase + (gt * g.Gh + gh) * g.Gw + gw) * g.cstride + cch) * 2u;
           }
         }
-        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : OOB, 0, 0);
+        offA[i] = ok ? off : OOB;
       }
     }
 #pragma unroll
-    for (int i = 0; i < NBI; ++i) {
-      const unsigned off = (k_ok && bbase[i] != OOB) ? bbase[i] + (unsigned)kcur * 2u : OOB;
-      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
-    }
+    for (int i = 0; i < NBI; ++i) offB[i] = (k_ok && bbase[i] != OOB) ? bbase[i] + (unsigned)kcur * 2u : OOB;
     kcur += BK;
     if (MODE != PP_DENSE) {
       cch += BK;
       while (cch >= g.cg) { cch -= g.cg; ++tap; }
     }
   };
+  auto load_stage = [&]() __attribute__((always_inline)) {
+    if (!RING) {
+      unsigned offA[NAI], offB[NBI];
+      stage_offsets(offA, offB);
+#pragma unroll
+      for (int i = 0; i < NAI; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[i], 0, 0);
+#pragma unroll
+      for (int i = 0; i < NBI; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[i], 0, 0);
+    }
+  };
+  // LDS-DMA: one wave-instruction lands 64 x 16 B = eight 128-byte rows, lane-linear from a wave-uniform base; lanes
+  // whose offset is OOB write zeros.  Every wave issues NAI pieces of A and NBI or NBI - 1 pieces of B per K-step.
+  const bool b_last = 8 * wave + RS * (NBI - 1) < BN;   // wave-uniform: does this wave own a piece in the last B pass
+  auto dma_stage = [&](unsigned char* buf) __attribute__((always_inline)) {
+    if (RING) {
+      unsigned offA[NAI], offB[NBI];
+      stage_offsets(offA, offB);
+      unsigned char* dst = buf + (8 * wave) * 128;
+#pragma unroll
+      for (int i = 0; i < NAI; ++i)
+        lds_dma16(rsA, dst + RS * i * 128, offA[i]);
+#pragma unroll
+      for (int i = 0; i < NBI; ++i)
+        if (i < NBI - 1 || b_last)
+          lds_dma16(rsB, dst + A_BYTES + RS * i * 128, offB[i]);
+    }
+  };
+  // wait until at most the newest stage of this wave's DMAs is still in flight (or none)
+  auto wait_stage = [&](const bool keep_one) __attribute__((always_inline)) {
+    if (!keep_one) wait_vmcnt<0>();
+    else if (b_last) wait_vmcnt<NAI + NBI>();
+    else wait_vmcnt<NAI + NBI - 1>();
+  };
   auto store_stage = [&](unsigned char* buf) __attribute__((always_inline)) {
+    if (RING) return;
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
       const int row = (tid >> 3) + RS * i;
@@ -258,7 +313,7 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
 
   // ---- epilogue of one finished tile (mb_e, nb_e); defined below the tile loop's helpers -------------------
   const int ncols_store = (p.N + 7) & ~7;
-  auto epilogue = [&](const int mb_e, const int nb_e) __attribute__((always_inline)) {
+  auto epilogue = [&](const int mb_e, const int nb_e, unsigned char* const ebuf) __attribute__((always_inline)) {
   // FULL = bias / activation / residual / pre-activation copy; otherwise plain store (+ optional
   // BatchNorm column statistics).  Flags are tested once, outside the per-value loops.
   const int m_wave = mb_e * BM + wave * 32;
@@ -309,7 +364,7 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
 
   // Each wave stages its own 16 x BN slab (bf16) in LDS and writes it out as full 16-byte row segments.
   // The slab is wave-private, so LDS program order (+ lgkmcnt waits) is the only synchronisation needed.
-  unsigned char* stg = smem + wave * 16 * STG_STRIDE;
+  unsigned char* stg = ebuf + wave * 16 * STG_STRIDE;
   unsigned char* stg_w = stg + (fq * 4) * STG_STRIDE + fr * 2;
   auto write_out = [&](bfraw* Cout, const bfraw* residual) __attribute__((always_inline)) {
 #pragma unroll
@@ -318,9 +373,10 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) *(bfraw*)(stg_w + r * STG_STRIDE + j * 32) = f2bf(acc[mt][j][r]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (RING) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a fence would also drain the LDS-DMAs in flight)
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
+#pragma unroll(FULL ? 1 : (32 * WN + 63) / 64)   // (rolled for the fused epilogues: their unrolled form spills)
       for (int it = 0; it < (32 * WN + 63) / 64; ++it) {
         const int cid = lane + 64 * it;
         const int row = cid / (2 * WN);
@@ -328,7 +384,16 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
         const int m = m_wave + mt * 16 + row;
         const int col = nb_e * BN + ch * 8;
         if (cid < 32 * WN && m < p.M && col < ncols_store) {
-          uint4 v = *(const uint4*)(stg + row * STG_STRIDE + ch * 16);
+          uint4 v;
+          if (RING) {
+            // (hipcc drains vmcnt -- the next tile's LDS-DMAs and every earlier store -- before a plain LDS load here)
+            const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(stg + row * STG_STRIDE + ch * 16);
+            u32x4 vv;   // (a native vector type: the host pass must accept the constraint as well)
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vv) : "v"(a) : "memory");
+            v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+          } else {
+            v = *(const uint4*)(stg + row * STG_STRIDE + ch * 16);
+          }
           long long orow = m;
           if (MODE != PP_DENSE && p.omap) {   // scatter compact rows of a parity class into the full tensor
             const uint32_t t1 = fdiv((uint32_t)m, rd.dRw);
@@ -351,7 +416,8 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
           *(uint4*)(Cout + c_off + orow * p.ldc + col) = v;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (RING) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       __builtin_amdgcn_wave_barrier();
     }
   };
@@ -365,7 +431,7 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
   if (p.colstats) {
     // per-column sum / sum of squares over this block's 128 rows (fp32 accumulators), deterministic:
     // in-lane over 8 rows, xor-shuffles over the 4 row groups, LDS over the 4 waves
-    float* statbuf = (float*)(smem + STG_BYTES);
+    float* statbuf = (float*)(ebuf + STG_BYTES);
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       float s1 = 0.f, s2 = 0.f;
@@ -386,7 +452,12 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
         statbuf[(wave * BN + j * 16 + fr) * 2 + 1] = s2;
       }
     }
-    __syncthreads();
+    if (RING) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
     // partial rows are always per 128 output rows (independent of the workgroup height)
     for (int idx = tid; idx < BN * (NW / 4); idx += NT) {
       const int c = idx % BN, h = idx / BN;
@@ -406,13 +477,54 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
   }
   };
 
-  // ---- tile loop: one register stage of global loads flies under the MFMAs of the current K-step; two LDS buffers,
-  // one barrier per 64-deep K-step; the next tile's first stage is issued before the epilogue
+  // ---- tile loop -------------------------------------------------------------------------------------------
   const int nk = (p.K + BK - 1) / BK;
   int it = 0;
   const int first = tile_index(0);
   if (first < 0) return;
   setup_tile(first);
+  if (RING) {
+    // K-step s (counted over all tiles of this workgroup) lives in slot s % 3.  Per step: wait for this wave's
+    // DMAs of the step (leaving the next one in flight), barrier (every wave's pieces have landed, and every wave
+    // is done reading the slot about to be refilled), issue the step after next, compute.
+    int s0 = 0;   // slot of this tile's first K-step
+    auto slot = [&](int s) __attribute__((always_inline)) { return smem + (s >= 3 ? s - 3 : s) * LOOP_BYTES; };
+    dma_stage(slot(s0));
+    if (nk > 1) dma_stage(slot(s0 + 1));
+    bool first_tile = true;
+    while (true) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int sl = s0;
+      for (int kt = 0; kt < nk; ++kt) {
+        // (the first step of a later tile also has the previous epilogue's stores on the counter: drain them all)
+        wait_stage(kt + 1 < nk && (kt > 0 || first_tile));
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) dma_stage(slot(sl + 2));
+        compute(slot(sl));
+        sl = sl == 2 ? 0 : sl + 1;
+      }
+      first_tile = false;
+      const int mb_done = mb, nb_done = nb;
+      const int next = tile_index(++it);
+      unsigned char* const last = slot(sl == 0 ? 2 : sl - 1);   // the slot just consumed stages the output
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // every wave is done reading it
+      if (next >= 0) {                // the next tile's first two K-steps fly under the epilogue
+        setup_tile(next);
+        dma_stage(slot(sl));
+        if (nk > 1) dma_stage(slot(sl + 1));
+      }
+      epilogue(mb_done, nb_done, last);
+      if (next < 0) break;
+      s0 = sl;
+    }
+    return;
+  }
+  // register staging: one stage of global loads flies under the MFMAs of the current K-step; two LDS buffers, one
+  // barrier per 64-deep K-step; the next tile's first stage is issued before a plain-store epilogue
   load_stage();
   while (true) {
 #pragma unroll
@@ -438,7 +550,7 @@ __global__ __launch_bounds__(64 * NW, (WN <= 9 ? 2 : 1)) void igemm_kernel(const
       setup_tile(next);
       load_stage();
     }
-    epilogue(mb_done, nb_done);
+    epilogue(mb_done, nb_done, smem);
     if (FULL || next < 0) break;   // fused epilogues run one tile per workgroup (the launcher sizes the grid so)
     __syncthreads();   // the staging slabs of the epilogue alias the loop buffers
   }
@@ -458,9 +570,20 @@ int pick_wn(int n16) {
   return best;
 }
 
-template <int WN, int NW>
-int launch_wn_nw(const pp_igemm_desc& d, hipStream_t s) {
-  constexpr int BM = 32 * NW;
+RowDiv make_rowdiv(const pp_igemm_desc& d) {
+  RowDiv rd;
+  const bool dense = d.g.mode == PP_DENSE;
+  rd.dRw = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rw));
+  rd.dRh = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rh));
+  rd.dRt = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rt));
+  return rd;
+}
+
+template <int WN>
+int launch_wn(const pp_igemm_desc& d, hipStream_t s) {
+  // 8-wave (256-row) register-staged workgroups were measured 3-10 % slower than 4-wave ones on the hot shapes, so
+  // that family only has 4-wave variants; the 256-row tiles belong to the LDS-DMA ring variant (launch_ring).
+  constexpr int NW = 4, BM = 32 * NW;
   const int nblk_n = (d.N + 16 * WN - 1) / (16 * WN);
   const long long nblk_m = ((long long)d.M + BM - 1) / BM;
   const long long ntiles = nblk_m * nblk_n;
@@ -472,14 +595,10 @@ int launch_wn_nw(const pp_igemm_desc& d, hipStream_t s) {
   long long gx = ntiles;
   if (pp_opt_persistent && !full && d.nbatch == 1 && ntiles >= 4 * resident) gx = resident;
   dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(64 * NW);
-  RowDiv rd;
-  const bool dense = d.g.mode == PP_DENSE;
-  rd.dRw = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rw));
-  rd.dRh = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rh));
-  rd.dRt = make_fastdiv((uint32_t)(dense ? 1 : d.g.Rt));
+  const RowDiv rd = make_rowdiv(d);
 #define PP_LAUNCH_IGEMM(MODE_)                                                                                       \
-  if (full) hipLaunchKernelGGL((igemm_kernel<WN, MODE_, true, NW>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles); \
-  else hipLaunchKernelGGL((igemm_kernel<WN, MODE_, false, NW>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles)
+  if (full) hipLaunchKernelGGL((igemm_kernel<WN, MODE_, true, NW, false>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles); \
+  else hipLaunchKernelGGL((igemm_kernel<WN, MODE_, false, NW, false>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles)
   switch (d.g.mode) {
     case PP_DENSE: PP_LAUNCH_IGEMM(PP_DENSE); break;
     case PP_CONV_FWD: PP_LAUNCH_IGEMM(PP_CONV_FWD); break;
@@ -491,11 +610,32 @@ int launch_wn_nw(const pp_igemm_desc& d, hipStream_t s) {
   return PP_OK;
 }
 
+// LDS-DMA ring variant: 256-row tiles, one persistent workgroup per CU
 template <int WN>
-int launch_wn(const pp_igemm_desc& d, hipStream_t s) {
-  // 8-wave (256-row) workgroups were measured 3-10 % slower than 4-wave ones on the hot shapes (more waves
-  // per barrier outweigh the halved weight-tile traffic), so only the 4-wave variant is instantiated.
-  return launch_wn_nw<WN, 4>(d, s);
+int launch_ring(const pp_igemm_desc& d, hipStream_t s) {
+  constexpr int BM = 256;
+  const int nblk_n = (d.N + 16 * WN - 1) / (16 * WN);
+  const long long nblk_m = ((long long)d.M + BM - 1) / BM;
+  const long long ntiles = nblk_m * nblk_n;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
+  const long long gx = ntiles < 256 ? ntiles : 256;
+  dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(512);
+  const RowDiv rd = make_rowdiv(d);
+  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
+#define PP_LAUNCH_RING(MODE_, FULL_) \
+  hipLaunchKernelGGL((igemm_kernel<WN, MODE_, FULL_, 8, true>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles)
+  switch (d.g.mode) {   // (fused epilogues: dense only -- the conv forms of the kernel would spill)
+    case PP_DENSE:
+      if (full) PP_LAUNCH_RING(PP_DENSE, true);
+      else PP_LAUNCH_RING(PP_DENSE, false);
+      break;
+    case PP_CONV_FWD: PP_LAUNCH_RING(PP_CONV_FWD, false); break;
+    case PP_CONV_DGRAD: PP_LAUNCH_RING(PP_CONV_DGRAD, false); break;
+    default: pp_set_error("pp_igemm: bad gather mode %d", d.g.mode); return PP_ERR_INVALID;
+  }
+#undef PP_LAUNCH_RING
+  PP_LAUNCH_CHECK();
+  return PP_OK;
 }
 
 }  // namespace
@@ -557,6 +697,15 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   PP_CHECK_ARG((long long)d.b_rows * d.ldb < 0x7ffffff0LL, "pp_igemm: Bt has >= 2^31 elements");
   hipStream_t s = (hipStream_t)stream;
   const int n16 = (d.N + 15) / 16;
+  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
+  if (pp_opt_ring && !d.c_fp32 && d.nbatch == 1 && n16 > 4 && d.K >= 2 * BK && (!full || d.g.mode == PP_DENSE)) {
+    // Ring tiles are 128 or 144 columns wide (whichever pads N less).  Narrow outputs (N <= 64) stay on the
+    // register-staged kernel, which measured faster there; so do GEMMs too small to give every CU a 256-row tile.
+    const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
+    const int best = c9 <= c8 ? 9 : 8;
+    const long long tiles = (((long long)d.M + 255) / 256) * ((n16 + best - 1) / best);
+    if (tiles >= pp_opt_ring) return best == 9 ? launch_ring<9>(d, s) : launch_ring<8>(d, s);
+  }
   switch (pick_wn(n16)) {
     case 15: return launch_wn<15>(d, s);
     case 9: return launch_wn<9>(d, s);

@@ -55,6 +55,9 @@ def gather_conv(mode, R, G, k, s, p, cg, cstride):
     return g
 
 
+RING_IGEMM_DEFAULT = 192   # pp_set_option("ring_igemm", n): LDS-DMA ring GEMM once there are n 256-row tiles (0 = never)
+
+
 # ---- optional in-process kernel timing (bench.py roofline): HIP events on the launch stream ----------
 PROFILE_ON = False
 PROFILE = {}
@@ -77,15 +80,17 @@ def _profiled(key, flops, fn):
     PROFILE.setdefault(key, []).append((e0, e1, flops))
 
 
-def profile_summary():
-    """(flops, seconds, launches, name) of the kernel family with the largest total time, or None."""
+def profile_summary(key=None):
+    """(flops, seconds, launches, name) of the kernel family with the largest total time (or of `key`), or None."""
     torch.cuda.synchronize()
     best = None
-    for key, recs in PROFILE.items():
+    for k, recs in PROFILE.items():
+        if key is not None and k != key:
+            continue
         secs = sum(a.elapsed_time(b) for a, b, _ in recs) * 1e-3
         fl = sum(f for _, _, f in recs)
         if best is None or secs > best[1]:
-            best = (fl, secs, len(recs), key)
+            best = (fl, secs, len(recs), k)
     return best
 
 

@@ -261,6 +261,7 @@ def run_plan(plan, cur, thw, B, training, save, first=False):
 
 
 _WGRAD_STREAMS = {}
+OVERLAP_WGRAD = True   # bench.py clears this for its isolated (one kernel at a time) roofline pass
 
 
 def _wgrad_stream(device):
@@ -276,7 +277,7 @@ def trunk_backward(tape, dz, grads, overlap_wgrad=True):
     unit), so it is issued on a side stream: the MFMA/latency-bound wgrad kernels then overlap the HBM-bound
     BatchNorm backward passes and the data-gradient GEMMs of the following units."""
     main = torch.cuda.current_stream()
-    side = _wgrad_stream(dz.device) if overlap_wgrad else None
+    side = _wgrad_stream(dz.device) if (overlap_wgrad and OVERLAP_WGRAD) else None
 
     def unit_bwd(rec, dz_in, relu, want_dres, dgrad_residual=None, need_dx=True):
         # units without a residual input recompute the ReLU mask from y (rec.has_res False -> z not read)

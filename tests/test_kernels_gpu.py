@@ -577,3 +577,46 @@ def test_strided_dgrad_with_residual_accumulate():
     dx = L.conv_dgrad(to_cl(dy, geom.out_cstride), geom, wd, residual=to_cl(res, geom.in_cstride))
     torch.cuda.synchronize()
     close(from_cl(dx, B, (T, Hh, W), Ci), x.grad + res, name="strided dgrad + residual")
+
+
+@pytest.mark.parametrize("case", [
+    # Ci, Co, k, s, p, B, T, H, W   (sizes that give several 256-row tiles per workgroup and ragged last tiles)
+    (64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), 3, 5, 56, 56),
+    (144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), 2, 7, 28, 30),
+    (128, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1), 1, 3, 13, 11),
+    (32, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1, 4, 9, 10),
+    (64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), 2, 3, 20, 22),
+])
+def test_ring_igemm_matches_register_staged(case):
+    """The LDS-DMA ring variant (256-row tiles, three-slot ring) is bit-identical to the register-staged kernel:
+    same K order, same MFMA sequence per output, same per-128-row statistics partials."""
+    Ci, Co, k, s, p, B, T, Hh, W = case
+    g = torch.Generator().manual_seed(Ci + 3 * Co)
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    x = (torch.randn(geom.Min, geom.in_cstride, generator=g)).to(torch.bfloat16).to(DEV)
+    x[:, Ci:] = 0
+    dy = (torch.randn(geom.M, geom.out_cstride, generator=g)).to(torch.bfloat16).to(DEV)
+    dy[:, Co:] = 0
+    w = torch.randn(Co, Ci, *k, generator=g).to(DEV) / math.sqrt(Ci * k[0] * k[1] * k[2])
+    wf, wd = L.prep_conv_weights(w, geom)
+    lin_w = torch.randn(Co, Ci, generator=g).to(DEV) * 0.05
+    lf, lt = L.prep_linear(lin_w)
+    xl = torch.randn(geom.M, lf.shape[1], generator=g).to(torch.bfloat16).to(DEV)
+    lbias = torch.randn(Co, generator=g).to(DEV)
+    res = torch.randn(geom.M, L.cpad(Co), generator=g).to(torch.bfloat16).to(DEV)
+    outs = []
+    try:
+        for ring in (0, 1):
+            H.set_option("ring_igemm", ring)
+            y, st = L.conv_fwd(x, geom, wf, stats=True)
+            dx = L.conv_dgrad(dy, geom, wd)
+            yl = L.linear_fwd(xl, geom.M, lf, Co)     # plain-epilogue dense GEMM
+            yf = L.linear_fwd(xl, geom.M, lf, Co, bias=lbias, act=H.ACT_GELU, residual=res)   # fused epilogue
+            torch.cuda.synchronize()
+            # (columns past cpad8(N) are not written)
+            outs.append((y.clone(), st.clone(), dx.clone(), yl[:, :Co].clone(), yf[:, :Co].clone()))
+    finally:
+        H.set_option("ring_igemm", H.RING_IGEMM_DEFAULT)
+    for a, b, name in zip(outs[0], outs[1], ("fwd", "colstats", "dgrad", "dense", "dense fused")):
+        assert a.shape == b.shape, name
+        assert torch.equal(a, b), f"{name}: ring differs from register-staged (max {(a.float() - b.float()).abs().max().item()})"
