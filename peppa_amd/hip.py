@@ -358,8 +358,10 @@ def bertadam_step(tl, chunk_tensor, chunk_off, n_chunks, chunk, norms, lr, b1, b
 def make_tensor_list(ps, gs, ms, vs, device):
     """Device-resident pointer tables for pp_bertadam_step; returns (TensorList, keepalive)."""
     n = len(ps)
-    tab = torch.tensor([[t.data_ptr() for t in ps], [t.data_ptr() for t in gs], [t.data_ptr() for t in ms],
-                        [t.data_ptr() for t in vs], [t.numel() for t in ps]], dtype=torch.int64).to(device)
+    # pinned + non_blocking: a pageable copy would block the host until the whole backward pass has drained
+    host = torch.tensor([[t.data_ptr() for t in ps], [t.data_ptr() for t in gs], [t.data_ptr() for t in ms],
+                         [t.data_ptr() for t in vs], [t.numel() for t in ps]], dtype=torch.int64).pin_memory()
+    tab = host.to(device, non_blocking=True)
     tl = TensorList()
     tl.n_tensors = n
     base = tab.data_ptr()

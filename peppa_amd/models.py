@@ -148,6 +148,35 @@ def _load_fairseq_checkpoint(path):
                        "state_dict with torchaudio parameter names.")
 
 
+def _video_trunk_launch(enc, x, save):
+    """Issue the trunk forward + spatial mean; returns (out (B,T',512) fp32, tape, dims)."""
+    net = enc.video
+    if save and not net.training:
+        raise RuntimeError("backward through eval-mode BatchNorm is not supported on the HIP path")
+    with torch.no_grad():
+        z, thw, tape = V.trunk_forward(net, x, enc.norm_kind, net.training, save)
+        B = x.shape[0]
+        Tn, HW = thw[0], thw[1] * thw[2]
+        out = torch.empty(B, Tn, 512, dtype=f32, device=x.device)
+        H.spatial_mean_fwd(z, out, B, Tn, HW, 512, z.shape[1])
+    return out, tape, (B, Tn, HW, z.shape[1])
+
+
+def prelaunch_video_trunk(enc, x):
+    """Issue the trunk forward of `enc` (R3DEncoder / ImageEncoder) NOW, ahead of the autograd node that will own it.
+
+    The next `enc(x)` with this very tensor adopts the result instead of launching again.  PeppaPig.encode_pair uses
+    this to put the long video kernels on the GPU before the host spends milliseconds issuing the audio tower, while
+    the video autograd node is still created after the audio one -- so the backward pass also starts with video."""
+    if not x.is_cuda:
+        raise H.PeppaHipError("peppa_amd.video needs a CUDA/HIP tensor (no CPU fallback)")
+    xc = x.contiguous().float()
+    params = enc.video.trunk_parameters()
+    save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    enc._prelaunched = (xc, save) + _video_trunk_launch(enc, xc, save)
+    return xc
+
+
 class VideoTrunkFn(torch.autograd.Function):
     """(B,3,T,H,W) fp32 in [0,1] -> spatial means of the trunk output, (B,T',512) fp32."""
 
@@ -156,17 +185,13 @@ class VideoTrunkFn(torch.autograd.Function):
         if not x.is_cuda:
             raise H.PeppaHipError("peppa_amd.video needs a CUDA/HIP tensor (no CPU fallback)")
         x = x.contiguous().float()
-        net = enc.video
         save = want_grad and any(ctx.needs_input_grad)  # grad mode is always off inside Function.forward
-        if save and not net.training:
-            raise RuntimeError("backward through eval-mode BatchNorm is not supported on the HIP path")
-        with torch.no_grad():
-            z, thw, tape = V.trunk_forward(net, x, enc.norm_kind, net.training, save)
-            B = x.shape[0]
-            Tn, HW = thw[0], thw[1] * thw[2]
-            out = torch.empty(B, Tn, 512, dtype=f32, device=x.device)
-            H.spatial_mean_fwd(z, out, B, Tn, HW, 512, z.shape[1])
-        ctx.tape, ctx.params, ctx.dims = tape, params, (B, Tn, HW, z.shape[1])
+        pre, enc._prelaunched = getattr(enc, "_prelaunched", None), None
+        if pre is not None and pre[0] is x and pre[1] == save:
+            out, tape, dims = pre[2:]       # kernels already in flight (PeppaPig.encode_pair): only adopt the tape
+        else:
+            out, tape, dims = _video_trunk_launch(enc, x, save)
+        ctx.tape, ctx.params, ctx.dims = tape, params, dims
         return out
 
     @staticmethod
@@ -312,10 +337,11 @@ class PeppaPig(_Base):
         if self._side_stream is None or self._side_stream.device != video.device:
             self._side_stream = torch.cuda.Stream(device=video.device)
         side = self._side_stream
-        side.wait_stream(main)
+        side.wait_stream(main)                                   # (the inputs; not the video kernels issued next)
+        video = prelaunch_video_trunk(self.video_encoder, video)  # long kernels first: the host runs ahead of them
         with torch.cuda.stream(side):
             A_ = self.encode_audio(audio)
-        V_ = self.encode_video(video)
+        V_ = self.encode_video(video)                            # adopts the launched trunk; node created after audio
         main.wait_stream(side)
         A_.record_stream(main)
         return V_, A_

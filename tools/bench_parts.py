@@ -31,3 +31,10 @@ def optim():
 print(f"video fwd+bwd {t(video):.1f} ms | video fwd (no grad) {t(video_fwd):.1f} ms")
 print(f"audio fwd+bwd {t(audio):.1f} ms | audio fwd (no grad) {t(audio_fwd):.1f} ms")
 print(f"full step {t(full):.1f} ms | optimizer {t(optim):.2f} ms")
+# host issue time vs device time: if the host needs as long to issue a step as the GPU to run it, the step is launch-bound
+def issue_time(fn, n=5):
+    fn(); fn(); torch.cuda.synchronize(); tot = 0.0
+    for _ in range(n):
+        t0 = time.perf_counter(); fn(); tot += time.perf_counter() - t0; torch.cuda.synchronize()
+    return tot / n * 1e3
+print(f"host issue time: video {issue_time(video):.1f} ms | audio {issue_time(audio):.1f} ms | full {issue_time(full):.1f} ms")
