@@ -12,6 +12,7 @@
 
 int pp_validate_gather(const pp_gather& g, int K, const char* who);
 extern int pp_opt_xcd_remap_wgrad;
+extern int pp_opt_ring_wgrad;
 
 namespace {
 
@@ -21,6 +22,7 @@ constexpr int QS = 288;   // Q row stride in bytes (256 + 32: 32*odd -> conflict
 constexpr unsigned OOB = 0xFFFFFFF0u;  // buffer offset that is always out of range -> loads zeros
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct WGeom {
   FastDiv dRw, dRh, dRt;
@@ -51,8 +53,10 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
   constexpr int BUF = P_BYTES + Q_BYTES;
   constexpr int NQI = 4;                                // Q chunks per thread and step
   constexpr int NPI = (WI * 128 + 255) / 256;           // P chunks per thread and step
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
-  __shared__ int lut[128];
+  // one LDS object: two loop buffers, the tap table and the four-deep row table (see decode_rows)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + 512 + 4 * MS * 8];
+  int* const lut = (int*)(smem + 2 * BUF);
+  int2* const rowtab = (int2*)(smem + 2 * BUF + 512);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware order (see igemm.hip): the (i, j) tiles of one M-split read the same dY / X rows, so keep
@@ -95,14 +99,42 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
   const int qrow = tid >> 4, qch = tid & 15;
   const int jq = j0 + qch * 8;
   const bool jq_ok = jq < p.Kj;
-  int qt0 = 0, qh0 = 0, qw0 = 0, cch = 0;
+  int qt0 = 0, qh0 = 0, qw0 = 0, cch = 0, qtap = 0;
+  unsigned tapoff = 0;   // byte offset of this thread's (tap, channel chunk) relative to a row's tap (0,0,0)
   if (MODE != PP_DENSE && jq_ok) {
-    const int tap = jq / g.cg;
+    qtap = jq / g.cg;
     cch = jq % g.cg;
-    const int e = lut[tap];
-    qt0 = (e & 0xff) - g.pt; qh0 = ((e >> 8) & 0xff) - g.ph; qw0 = ((e >> 16) & 0xff) - g.pw;
+    const int e = lut[qtap];
+    const int dt = e & 0xff, dh = (e >> 8) & 0xff, dw = (e >> 16) & 0xff;
+    qt0 = dt - g.pt; qh0 = dh - g.ph; qw0 = dw - g.pw;
+    tapoff = (unsigned)((((dt * g.Gh + dh) * g.Gw + dw) * g.cstride + cch) * 2);
   }
-  auto q_offset = [&](int m) __attribute__((always_inline)) -> unsigned {
+  // Row table (conv gathers with <= 32 taps): the address arithmetic of a row -- three exact divisions, the origin
+  // offset and the validity of every tap -- is done ONCE per row and step by one lane and shared through LDS,
+  // instead of by each of the 16 lanes that fetch the row's chunks.  Entry = {byte offset of tap (0,0,0) (may be
+  // "virtual", i.e. outside the tensor), bit t set <=> tap t lies inside the tensor}.
+  const bool use_tab = MODE != PP_DENSE && ntaps <= 32;
+  auto decode_rows = [&](const int mbase, const int par) __attribute__((always_inline)) {
+    const int m = mbase + lane;
+    int base = 0;
+    unsigned mask = 0;
+    if (m < m_end) {
+      const uint32_t t1 = fdiv((uint32_t)m, wg.dRw);
+      const int rw = m - (int)t1 * g.Rw;
+      const uint32_t t2 = fdiv(t1, wg.dRh);
+      const int rh = (int)t1 - (int)t2 * g.Rh;
+      const int n = (int)fdiv(t2, wg.dRt);
+      const int rt = (int)t2 - n * g.Rt;
+      const int ct = rt * g.st - g.pt, chh = rh * g.sh - g.ph, cw = rw * g.sw - g.pw;
+      base = ((((n * g.Gt + ct) * g.Gh + chh) * g.Gw + cw) * g.cstride) * 2;
+      unsigned vw = 0, mhw = 0;
+      for (int d = 0; d < g.kw; ++d) vw |= (unsigned)((unsigned)(cw + d) < (unsigned)g.Gw) << d;
+      for (int d = 0; d < g.kh; ++d) mhw |= ((unsigned)(chh + d) < (unsigned)g.Gh) ? vw << (d * g.kw) : 0u;
+      for (int d = 0; d < g.kt; ++d) mask |= ((unsigned)(ct + d) < (unsigned)g.Gt) ? mhw << (d * g.kh * g.kw) : 0u;
+    }
+    rowtab[par * MS + lane] = make_int2(base, (int)mask);
+  };
+  auto q_offset = [&](int m) __attribute__((always_inline)) -> unsigned {   // direct form (dense, or > 32 taps)
     if (!jq_ok || m >= m_end) return OOB;
     if (MODE == PP_DENSE) return (unsigned)(m * g.lda + jq) * 2u;
     const uint32_t t1 = fdiv((uint32_t)m, wg.dRw);
@@ -136,27 +168,40 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
 #pragma unroll
     for (int q = 0; q < 8; ++q) bsum[it][q] = 0.f;
 
-  u32x4 rq[NQI], rp[NPI];
-  auto load_stage = [&](int mbase) __attribute__((always_inline)) {
+  // Two register sets: the loads of steps s + 1 and s + 2 are in flight while step s is multiplied (an HBM miss
+  // costs ~2 us here, several 64-row steps).  `set` is a literal at every call site.
+  u32x4 rq[2][NQI], rp[2][NPI];
+  auto load_stage = [&](const int set, const int step) __attribute__((always_inline)) {
+    const int mbase = m_begin + step * MS;
+    if (use_tab) {
+      const int par = step & 3;
 #pragma unroll
-    for (int i = 0; i < NQI; ++i) rq[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, q_offset(mbase + qrow + 16 * i), 0, 0);
+      for (int i = 0; i < NQI; ++i) {
+        const int2 e = rowtab[par * MS + qrow + 16 * i];   // (rows past m_end carry an empty mask)
+        const bool ok = jq_ok && (((unsigned)e.y >> qtap) & 1u);
+        rq[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? (unsigned)e.x + tapoff : OOB, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NQI; ++i) rq[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, q_offset(mbase + qrow + 16 * i), 0, 0);
+    }
 #pragma unroll
     for (int it = 0; it < NPI; ++it) {
       const int m = mbase + prow[it];
       const int i = i0 + pch[it] * 8;
       const bool ok = prow[it] < MS && m < m_end && i < p.ldy;
-      rp[it] = __builtin_amdgcn_raw_buffer_load_b128(rsY, ok ? (unsigned)(m * p.ldy + i) * 2u : OOB, 0, 0);
+      rp[set][it] = __builtin_amdgcn_raw_buffer_load_b128(rsY, ok ? (unsigned)(m * p.ldy + i) * 2u : OOB, 0, 0);
     }
   };
-  auto store_stage = [&](unsigned char* buf) __attribute__((always_inline)) {
+  auto store_stage = [&](const int set, unsigned char* buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NQI; ++i) *(u32x4*)(buf + P_BYTES + (qrow + 16 * i) * QS + qch * 16) = rq[i];
+    for (int i = 0; i < NQI; ++i) *(u32x4*)(buf + P_BYTES + (qrow + 16 * i) * QS + qch * 16) = rq[set][i];
 #pragma unroll
     for (int it = 0; it < NPI; ++it) {
-      if (prow[it] < MS) *(u32x4*)(buf + prow[it] * PS + pch[it] * 16) = rp[it];
+      if (prow[it] < MS) *(u32x4*)(buf + prow[it] * PS + pch[it] * 16) = rp[set][it];
       if (BIAS && do_bias) {
         float f[8];
-        unpack8(make_uint4(rp[it][0], rp[it][1], rp[it][2], rp[it][3]), f);
+        unpack8(make_uint4(rp[set][it][0], rp[set][it][1], rp[set][it][2], rp[set][it][3]), f);
 #pragma unroll
         for (int q = 0; q < 8; ++q) bsum[BIAS ? it : 0][q] += f[q];
       }
@@ -183,21 +228,30 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
 
   // one register stage of loads in flight under the MFMAs, two LDS buffers, one barrier per 64-row step
   const int nsteps = (m_end - m_begin + MS - 1) / MS;
-  if (nsteps > 0) {
-    load_stage(m_begin);
-    store_stage(smem);
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int st = 0; st < nsteps; ++st) {
-    const bool more = st + 1 < nsteps;
-    if (more) load_stage(m_begin + (st + 1) * MS);
-    compute(smem + cur * BUF);
-    cur ^= 1;
-    if (more) store_stage(smem + cur * BUF);
+  if (use_tab) {   // row tables of steps 0..3 (step s lives in table s & 3)
+    decode_rows(m_begin + wave * MS, wave);
     __syncthreads();
   }
-
+  // Pipeline: step s is loaded into register set s & 1 three iterations ahead, written to LDS buffer s & 1 after step
+  // s - 1 has been multiplied, multiplied one iteration later.  (Loads past the last step fetch nothing: every lane
+  // is out of range.)
+  load_stage(0, 0);
+  store_stage(0, smem);
+  load_stage(1, 1);
+  load_stage(0, 2);
+  __syncthreads();
+  auto iteration = [&](const int st, const int set, unsigned char* cur, unsigned char* nxt) __attribute__((always_inline)) {
+    // the row table of step st (read three iterations ago) is free: refill it for step st + 4
+    if (use_tab && wave == (st & 3)) decode_rows(m_begin + (st + 4) * MS, st & 3);
+    compute(cur);
+    store_stage(set, nxt);          // step st + 1: waits for its own loads only
+    load_stage(set, st + 3);        // ... and its registers go straight back into flight
+    __syncthreads();
+  };
+  for (int st = 0; st < nsteps; st += 2) {
+    iteration(st, 1, smem, smem + BUF);
+    if (st + 1 < nsteps) iteration(st + 1, 0, smem + BUF, smem);
+  }
   if (BIAS) {
     // bias gradient: combine the block's row-threads in LDS first, then ONE global atomic per column
     float* bred = (float*)smem;   // the loop buffers are free after the final barrier
@@ -244,6 +298,298 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
       for (int h = 0; h < 2; ++h) {
         const int j = j0 + h * 64 + lane;
         if (j < p.Kj) atomicAdd(dW + (long long)i * p.ldw + j, tile[row * TJ + h * 64 + lane]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA ring variant: one persistent-size workgroup per CU (NWV waves, TJ = 32 * NWV columns of dW), operands go
+// global -> LDS by buffer_load ... lds into a three-slot ring with two 64-row steps in flight across raw barriers
+// (counted vmcnt), exactly as in igemm.hip's ring.  A DMA piece is 1 KiB, lane-linear, so a lane's (row, chunk) in a
+// padded slab row comes from dividing its LDS offset by the row stride; pad lanes fetch OOB (zeros).
+// The fused bias gradient needs no extra loads: the wave that owns j-tiles 0,1 multiplies every dY fragment with a
+// fragment of ones on the matrix core (column 0 of that accumulator is the column sum).
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) buffer_rsrc;
+
+__device__ __forceinline__ void lds_dma16(const buffer_rsrc rs, unsigned char* dst, const unsigned off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, off, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (conservative)
+  }
+}
+
+template <int WI, int NWV, int MODE, bool BIAS>
+__global__ __launch_bounds__(64 * NWV, 1) void wgrad_ring_kernel(const pp_wgrad_desc p, const WGeom wg, const int nblk_i,
+                                                                   const int nblk_j, const int rows_per_split,
+                                                                   const int xcd_remap) {
+  constexpr int NT = 64 * NWV;
+  constexpr int TJR = 32 * NWV;                                   // columns of dW per workgroup
+  constexpr int TI = 16 * WI;
+  constexpr int PS = (WI & 1) ? TI * 2 : TI * 2 + 32;             // slab row strides: 32 bytes x odd
+  constexpr int QSR = (NWV & 1) ? TJR * 2 : TJR * 2 + 32;
+  constexpr int P_BYTES = MS * PS, Q_BYTES = MS * QSR;
+  constexpr int SLOT = P_BYTES + Q_BYTES;
+  constexpr int NPIECE_P = P_BYTES / 1024, NPIECE_Q = Q_BYTES / 1024;
+  static_assert(P_BYTES % 1024 == 0 && Q_BYTES % 1024 == 0, "slabs are whole DMA pieces");
+  constexpr int NPP = (NPIECE_P + NWV - 1) / NWV, NPQ = (NPIECE_Q + NWV - 1) / NWV;   // pieces per wave and step
+  static_assert(3 * SLOT + 512 <= 160 * 1024, "ring does not fit the LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SLOT + 512];   // one LDS object (see igemm.hip)
+  int* const lut = (int*)(smem + 3 * SLOT);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid;
+  {
+    const int nwg = gridDim.x, b0 = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = b0 & 7;
+    bid = xcd_remap ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b0 >> 3) : b0;
+  }
+  const int ib = bid % nblk_i; bid /= nblk_i;
+  const int jb = bid % nblk_j; bid /= nblk_j;
+  const int split = bid;
+  const bfraw* X = (const bfraw*)p.X;
+  const bfraw* dY = (const bfraw*)p.dY;
+  float* __restrict__ dW = p.dW;
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)OOB, 0x00020000);
+  const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, (short)0, (int)OOB, 0x00020000);
+  const pp_gather& g = p.g;
+  const int ntaps = g.kt * g.kh * g.kw;
+  if (MODE != PP_DENSE) {
+    if (tid < 128) {
+      int e = 0;
+      if (tid < ntaps) {
+        const int dw = tid % g.kw;
+        const int t2 = tid / g.kw;
+        e = (t2 / g.kh) | ((t2 % g.kh) << 8) | (dw << 16);
+      }
+      lut[tid] = e;
+    }
+    __syncthreads();
+  }
+  const int i0 = ib * TI, j0 = jb * TJR;
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(p.M, m_begin + rows_per_split);
+
+  // ---- this lane's slot in each DMA piece its wave issues -----------------------------------------------------
+  int p_row[NPP];
+  unsigned p_col[NPP];        // byte offset of the chunk inside a dY row, or OOB for pad / out-of-range columns
+  int np_w = 0;               // pieces of P this wave really issues (wave-uniform)
+#pragma unroll
+  for (int it = 0; it < NPP; ++it) {
+    const int piece = wave + NWV * it;
+    const int o = piece * 1024 + lane * 16;
+    p_row[it] = o / PS;
+    const int cb = o % PS;
+    const int i = i0 + cb / 2;
+    p_col[it] = (cb < TI * 2 && i < p.ldy) ? (unsigned)i * 2u : OOB;
+    if (piece < NPIECE_P) ++np_w;
+  }
+  int q_row[NPQ], q_t0[NPQ], q_h0[NPQ], q_w0[NPQ];
+  unsigned q_col[NPQ];        // dense: byte offset inside an X row; conv: channel byte offset inside the tap; OOB = pad
+  int nq_w = 0;
+#pragma unroll
+  for (int it = 0; it < NPQ; ++it) {
+    const int piece = wave + NWV * it;
+    const int o = piece * 1024 + lane * 16;
+    q_row[it] = o / QSR;
+    const int cb = o % QSR;
+    const int jq = j0 + cb / 2;
+    const bool ok = cb < TJR * 2 && jq < p.Kj;
+    q_t0[it] = q_h0[it] = q_w0[it] = 0;
+    if (MODE == PP_DENSE) {
+      q_col[it] = ok ? (unsigned)jq * 2u : OOB;
+    } else {
+      q_col[it] = OOB;
+      if (ok) {
+        const int tap = jq / g.cg;
+        q_col[it] = (unsigned)(jq - tap * g.cg) * 2u;
+        const int e = lut[tap];
+        q_t0[it] = (e & 0xff) - g.pt; q_h0[it] = ((e >> 8) & 0xff) - g.ph; q_w0[it] = ((e >> 16) & 0xff) - g.pw;
+      }
+    }
+    if (piece < NPIECE_Q) ++nq_w;
+  }
+  const int per_step = __builtin_amdgcn_readfirstlane(np_w + nq_w);   // DMA instructions this wave issues per step
+
+  auto dma_stage = [&](unsigned char* buf, const int mbase) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NPP; ++it) {
+      if (it < np_w) {
+        const int m = mbase + p_row[it];
+        const unsigned off = (p_col[it] != OOB & m < m_end) ? (unsigned)(m * p.ldy) * 2u + p_col[it] : OOB;
+        lds_dma16(rsY, buf + (wave + NWV * it) * 1024, off);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NPQ; ++it) {
+      if (it < nq_w) {
+        const int m = mbase + q_row[it];
+        const bool live = q_col[it] != OOB && m < m_end;
+        unsigned off;   // (branch-free: everything is computed, then selected)
+        if (MODE == PP_DENSE) {
+          off = (unsigned)(m * g.lda) * 2u + q_col[it];
+        } else {
+          const uint32_t t1 = fdiv((uint32_t)m, wg.dRw);
+          const int rw = m - (int)t1 * g.Rw;
+          const uint32_t t2 = fdiv(t1, wg.dRh);
+          const int rh = (int)t1 - (int)t2 * g.Rh;
+          const int n = (int)fdiv(t2, wg.dRt);
+          const int rt = (int)t2 - n * g.Rt;
+          const int gt = rt * g.st + q_t0[it], gh = rh * g.sh + q_h0[it], gw = rw * g.sw + q_w0[it];
+          const bool in = (unsigned)gt < (unsigned)g.Gt & (unsigned)gh < (unsigned)g.Gh & (unsigned)gw < (unsigned)g.Gw;
+          off = (unsigned)((((n * g.Gt + gt) * g.Gh + gh) * g.Gw + gw) * g.cstride) * 2u + q_col[it];
+          off = in ? off : OOB;
+        }
+        off = live ? off : OOB;
+        lds_dma16(rsX, buf + P_BYTES + (wave + NWV * it) * 1024, off);
+      }
+    }
+  };
+
+  f32x4 acc[WI][2];
+#pragma unroll
+  for (int a = 0; a < WI; ++a) acc[a][0] = acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = BIAS && jb == 0 && wave == 0;
+  f32x4 bacc[BIAS ? WI : 1];
+#pragma unroll
+  for (int a = 0; a < (BIAS ? WI : 1); ++a) bacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.0f;
+
+  // Fragment reads go through inline asm: hipcc drains vmcnt (every LDS-DMA in flight) before a
+  // ds_read_b64_tr_b16 issued through the builtin, which would serialise the ring.  The asm reads are invisible to
+  // the compiler's counters, hence the explicit lgkmcnt waits; the second half-step's reads are issued ahead of the
+  // first half-step's MFMAs so their latency is covered.
+  const int gq = lane >> 4, li = lane & 15;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
+  const unsigned p_lane = (unsigned)((4 * gq + (li >> 2)) * PS + (li & 3) * 8);    // tr_frag's address pattern
+  const unsigned q_lane = (unsigned)((4 * gq + (li >> 2)) * QSR + (li & 3) * 8 + (2 * wave) * 32);
+  // A fragment = two 64-bit transposing reads (rows 0-15 / 16-31 of the half-step); the raw halves stay in their own
+  // registers until the wait below has "modified" them, so nothing the compiler derives from them (the 4-register
+  // MFMA operand tuples) can be scheduled ahead of the data's arrival.
+  struct Frags { u32x2 ql[2], qh[2], pl[WI], ph[WI]; };
+  auto read_frags = [&](const unsigned slot_off, const int sub, Frags& f) __attribute__((always_inline)) {
+    const unsigned pa = lds0 + slot_off + (unsigned)(sub * 32 * PS) + p_lane;
+    const unsigned qa = lds0 + slot_off + (unsigned)(P_BYTES + sub * 32 * QSR) + q_lane;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.ql[jj]) : "v"(qa + jj * 32) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.qh[jj]) : "v"(qa + jj * 32 + 16 * QSR) : "memory");
+    }
+#pragma unroll
+    for (int a = 0; a < WI; ++a) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.pl[a]) : "v"(pa + a * 32) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.ph[a]) : "v"(pa + a * 32 + 16 * PS) : "memory");
+    }
+  };
+  auto wait_frags = [&](Frags& f) __attribute__((always_inline)) {
+    static_assert(WI == 8 || WI == 9, "operand list below");
+    if constexpr (WI == 9) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(f.ql[0]), "+v"(f.qh[0]), "+v"(f.ql[1]), "+v"(f.qh[1]), "+v"(f.pl[0]), "+v"(f.ph[0]), "+v"(f.pl[1]),
+                     "+v"(f.ph[1]), "+v"(f.pl[2]), "+v"(f.ph[2]), "+v"(f.pl[3]), "+v"(f.ph[3]), "+v"(f.pl[4]), "+v"(f.ph[4]),
+                     "+v"(f.pl[5]), "+v"(f.ph[5]), "+v"(f.pl[6]), "+v"(f.ph[6]), "+v"(f.pl[7]), "+v"(f.ph[7]),
+                     "+v"(f.pl[WI - 1]), "+v"(f.ph[WI - 1])
+                   :
+                   : "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(f.ql[0]), "+v"(f.qh[0]), "+v"(f.ql[1]), "+v"(f.qh[1]), "+v"(f.pl[0]), "+v"(f.ph[0]), "+v"(f.pl[1]),
+                     "+v"(f.ph[1]), "+v"(f.pl[2]), "+v"(f.ph[2]), "+v"(f.pl[3]), "+v"(f.ph[3]), "+v"(f.pl[4]), "+v"(f.ph[4]),
+                     "+v"(f.pl[5]), "+v"(f.ph[5]), "+v"(f.pl[6]), "+v"(f.ph[6]), "+v"(f.pl[7]), "+v"(f.ph[7])
+                   :
+                   : "memory");
+    }
+  };
+  auto mfma_frags = [&](const Frags& f) __attribute__((always_inline)) {
+    bf16x8 qf[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) qf[jj] = __builtin_bit_cast(bf16x8, (u32x4){f.ql[jj][0], f.ql[jj][1], f.qh[jj][0], f.qh[jj][1]});
+#pragma unroll
+    for (int a = 0; a < WI; ++a) {
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, (u32x4){f.pl[a][0], f.pl[a][1], f.ph[a][0], f.ph[a][1]});
+      acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[0], acc[a][0], 0, 0, 0);
+      acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[1], acc[a][1], 0, 0, 0);
+      if (BIAS && do_bias) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, ones, bacc[a], 0, 0, 0);
+    }
+  };
+  auto compute = [&](const unsigned slot_off) __attribute__((always_inline)) {
+    Frags f0, f1;
+    read_frags(slot_off, 0, f0);
+    wait_frags(f0);
+    read_frags(slot_off, 1, f1);   // in flight under the first half-step's MFMAs
+    mfma_frags(f0);
+    wait_frags(f1);
+    mfma_frags(f1);
+  };
+
+  const int nsteps = (m_end - m_begin + MS - 1) / MS;
+  if (nsteps > 0) dma_stage(smem, m_begin);
+  if (nsteps > 1) dma_stage(smem + SLOT, m_begin + MS);
+  int sl = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    wait_vmcnt_dyn(st + 1 < nsteps ? per_step : 0);   // this wave's pieces of step st have landed
+    __builtin_amdgcn_s_barrier();                      // ... and everyone's; slot (st + 2) % 3 is free again
+    if (st + 2 < nsteps) dma_stage(smem + (sl >= 1 ? sl - 1 : 2) * SLOT, m_begin + (st + 2) * MS);
+    compute((unsigned)(sl * SLOT));
+    sl = sl == 2 ? 0 : sl + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  if (BIAS && do_bias && fr == 0) {   // column 0 of each bias accumulator holds the column sums of dY
+#pragma unroll
+    for (int a = 0; a < WI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + a * 16 + fq * 4 + r;
+        if (i < p.Ni) atomicAdd(p.dbias + i, bacc[a][r]);
+      }
+  }
+  // fp32 tile through LDS so that every atomic wave-instruction adds 256 contiguous bytes
+  float* tile = (float*)smem;
+  constexpr int CHMAX = (3 * SLOT) / (16 * TJR * 4);
+  constexpr int CH = CHMAX < WI ? CHMAX : WI;
+#pragma unroll
+  for (int a0 = 0; a0 < WI; a0 += CH) {
+    if (a0 > 0) __syncthreads();
+#pragma unroll
+    for (int a = a0; a < a0 + CH && a < WI; ++a)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          tile[((a - a0) * 16 + fq * 4 + r) * TJR + (2 * wave + jj) * 16 + fr] = acc[a][jj][r];
+    __syncthreads();
+    const int nrows = (WI - a0 < CH ? WI - a0 : CH) * 16;
+    const int nq = (nrows + NWV - 1) / NWV;
+    for (int k = 0; k < nq; ++k) {
+      const int row = ((k + split * 7) % nq) * NWV + wave;   // splits start at different rows (see above)
+      const int i = i0 + a0 * 16 + row;
+      if (row >= nrows || i >= p.Ni) continue;
+#pragma unroll
+      for (int h = 0; h < TJR / 64; ++h) {
+        const int j = j0 + h * 64 + lane;
+        if (j < p.Kj) atomicAdd(dW + (long long)i * p.ldw + j, tile[row * TJR + h * 64 + lane]);
       }
     }
   }
@@ -297,6 +643,41 @@ int launch_wi(const pp_wgrad_desc& d, hipStream_t s) {
   return PP_OK;
 }
 
+template <int WI, int NWV>
+int launch_ring(const pp_wgrad_desc& d, hipStream_t s) {
+  constexpr int TJR = 32 * NWV;
+  const int nblk_i = (d.Ni + 16 * WI - 1) / (16 * WI);
+  const int nblk_j = (d.Kj + TJR - 1) / TJR;
+  const long long steps = ((long long)d.M + MS - 1) / MS;
+  const long long tiles = (long long)nblk_i * nblk_j;
+  // one workgroup per CU: pick the M split that fills whole rounds of 256 workgroups best, >= 16 steps per split
+  long long best = 1;
+  double best_eff = 0.0;
+  const long long maxs = steps / 16 > 0 ? steps / 16 : 1;
+  for (long long ms = 1; ms <= maxs && ms * tiles <= 4096; ++ms) {
+    const long long gx = ms * tiles;
+    const double eff = (double)gx / (double)(((gx + 255) / 256) * 256) - 0.002 * (double)ms;   // splits cost atomics
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = ms; }
+  }
+  int msplit = d.msplit > 0 ? d.msplit : (int)best;
+  const long long sps = (steps + msplit - 1) / msplit;
+  msplit = (int)((steps + sps - 1) / sps);
+  const int rows_per_split = (int)(sps * MS);
+  WGeom wg;
+  wg.dRw = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rw));
+  wg.dRh = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rh));
+  wg.dRt = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rt));
+  dim3 grid((unsigned)(tiles * msplit), 1, 1), block(64 * NWV);
+  if (d.g.mode == PP_DENSE) {
+    if (d.dbias) hipLaunchKernelGGL((wgrad_ring_kernel<WI, NWV, PP_DENSE, true>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+    else hipLaunchKernelGGL((wgrad_ring_kernel<WI, NWV, PP_DENSE, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+  } else {
+    hipLaunchKernelGGL((wgrad_ring_kernel<WI, NWV, PP_CONV_FWD, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+  }
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
 }  // namespace
 
 extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
@@ -321,7 +702,16 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
                  "pp_wgrad: gathered tensor >= 2^31 elements or M not a multiple of Rt*Rh*Rw");
   }
   hipStream_t s = (hipStream_t)stream;
-  switch (pick_wi((d.Ni + 15) / 16)) {
+  const int n16 = (d.Ni + 15) / 16;
+  if (pp_opt_ring_wgrad && d.nbatch == 1 && n16 > 4 && (long long)d.M >= pp_opt_ring_wgrad) {
+    // ring tiles: 128 or 144 rows of dW (less padding wins) x 192 or 256 columns (ditto; 192 on ties)
+    const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
+    const int j6 = ((d.Kj + 191) / 192) * 192, j8 = ((d.Kj + 255) / 256) * 256;
+    const bool w9 = c9 <= c8, v6 = j6 <= j8;
+    if (w9) return v6 ? launch_ring<9, 6>(d, s) : launch_ring<9, 8>(d, s);
+    return v6 ? launch_ring<8, 6>(d, s) : launch_ring<8, 8>(d, s);
+  }
+  switch (pick_wi(n16)) {
     case 15: return launch_wi<15>(d, s);
     case 9: return launch_wi<9>(d, s);
     case 8: return launch_wi<8>(d, s);

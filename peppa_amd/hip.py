@@ -55,6 +55,7 @@ def gather_conv(mode, R, G, k, s, p, cg, cstride):
     return g
 
 
+RING_WGRAD_DEFAULT = 0     # pp_set_option("ring_wgrad", n): LDS-DMA ring weight gradient once M >= n rows (0 = never)
 RING_IGEMM_DEFAULT = 192   # pp_set_option("ring_igemm", n): LDS-DMA ring GEMM once there are n 256-row tiles (0 = never)
 
 

@@ -620,3 +620,41 @@ def test_ring_igemm_matches_register_staged(case):
     for a, b, name in zip(outs[0], outs[1], ("fwd", "colstats", "dgrad", "dense", "dense fused")):
         assert a.shape == b.shape, name
         assert torch.equal(a, b), f"{name}: ring differs from register-staged (max {(a.float() - b.float()).abs().max().item()})"
+
+
+@pytest.mark.parametrize("case", [
+    # Ci, Co, k, s, p, B, T, H, W
+    (64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), 2, 4, 28, 30),     # Kj = 576 = 3 x 192
+    (128, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1), 1, 3, 13, 11),    # two row blocks of dW, ragged M
+    (230, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), 2, 6, 9, 9),      # Kj = 720, strided temporal gather
+    (48, 160, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1, 4, 9, 10),      # 27 taps: 256-column tiles
+])
+def test_ring_wgrad_matches_register_staged(case):
+    """LDS-DMA ring weight gradient (192/256-column tiles, inline-asm transposing LDS reads) against the register-staged
+    kernel: same products, different fp32 summation order (M split + atomics), so equal to fp32 rounding."""
+    Ci, Co, k, s, p, B, T, Hh, W = case
+    g = torch.Generator().manual_seed(11 * Ci + Co)
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    x = torch.randn(geom.Min, geom.in_cstride, generator=g).to(torch.bfloat16).to(DEV)
+    x[:, Ci:] = 0
+    dy = torch.randn(geom.M, geom.out_cstride, generator=g).to(torch.bfloat16).to(DEV)
+    dy[:, Co:] = 0
+    xl = torch.randn(geom.M, L.cpad(Ci), generator=g).to(torch.bfloat16).to(DEV)
+    outs = []
+    try:
+        for ring in (0, 1):
+            H.set_option("ring_wgrad", ring)
+            gw = L.conv_wgrad_raw(x, dy, geom)
+            dwl, dbl = L.linear_wgrad(xl, dy, geom.M, Co, xl.shape[1], want_bias=True)
+            torch.cuda.synchronize()
+            outs.append((gw.clone(), dwl.clone(), dbl.clone()))
+    finally:
+        H.set_option("ring_wgrad", H.RING_WGRAD_DEFAULT)
+    for a, b, name in zip(outs[0], outs[1], ("conv wgrad", "dense wgrad", "bias grad")):
+        scale = a.abs().max().item()
+        err = (a - b).abs().max().item()
+        assert err <= 2e-5 * scale + 1e-6, f"{name}: ring differs by {err} (scale {scale})"
+    # and against plain fp32 PyTorch for the dense pair
+    ref = dy.float()[:, :Co].t() @ xl.float()
+    close(outs[1][1][:, :xl.shape[1]], ref, name="ring dense wgrad vs torch")
+    close(outs[1][2], dy.float()[:, :Co].sum(0), name="ring bias grad vs torch")
