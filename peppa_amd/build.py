@@ -41,6 +41,9 @@ def build_library(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    # dlopen in a child process: an unresolved symbol (e.g. a kernel stub the host pass dropped) must fail the build
+    # here, not the first call on the GPU box
+    subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({OUT!r})"], check=True)
     return OUT
 
 

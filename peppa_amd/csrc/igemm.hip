@@ -17,12 +17,14 @@
 
 int pp_opt_xcd_remap_igemm = 1;
 int pp_opt_persistent = 1;
+int pp_opt_sw_wgrad = 4096;    // sliding-window weight gradient for (1,3,3) stride-1 convs once M >= this (0 = never)
 int pp_opt_ring_wgrad = 0;      // LDS-DMA ring weight gradient once the reduce dimension has this many rows (0 = never)
 int pp_opt_ring = 192; // LDS-DMA ring variant once there are this many 256-row tiles (0 = never)
 int pp_opt_xcd_remap_wgrad = 1;
 extern "C" int pp_set_option(const char* name, int value) {
   if (!name) return PP_ERR_INVALID;
   if (!strcmp(name, "xcd_remap_igemm")) { pp_opt_xcd_remap_igemm = value; return PP_OK; }
+  if (!strcmp(name, "sw_wgrad")) { pp_opt_sw_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_wgrad")) { pp_opt_ring_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_igemm")) { pp_opt_ring = value; return PP_OK; }
   if (!strcmp(name, "persistent_igemm")) { pp_opt_persistent = value; return PP_OK; }

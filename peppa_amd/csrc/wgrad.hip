@@ -13,6 +13,8 @@
 int pp_validate_gather(const pp_gather& g, int K, const char* who);
 extern int pp_opt_xcd_remap_wgrad;
 extern int pp_opt_ring_wgrad;
+extern int pp_opt_sw_wgrad;
+int pp_wgrad_sw_try(const pp_wgrad_desc& d, hipStream_t s);
 
 namespace {
 
@@ -702,6 +704,10 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
                  "pp_wgrad: gathered tensor >= 2^31 elements or M not a multiple of Rt*Rh*Rw");
   }
   hipStream_t s = (hipStream_t)stream;
+  if (pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad) {   // (1,3,3) stride-1 convs: sliding-window kernel
+    const int rc_sw = pp_wgrad_sw_try(d, s);
+    if (rc_sw != 1) return rc_sw;
+  }
   const int n16 = (d.Ni + 15) / 16;
   if (pp_opt_ring_wgrad && d.nbatch == 1 && n16 > 4 && (long long)d.M >= pp_opt_ring_wgrad) {
     // ring tiles: 128 or 144 rows of dW (less padding wins) x 192 or 256 columns (ditto; 192 on ties)

@@ -658,3 +658,39 @@ def test_ring_wgrad_matches_register_staged(case):
     ref = dy.float()[:, :Co].t() @ xl.float()
     close(outs[1][1][:, :xl.shape[1]], ref, name="ring dense wgrad vs torch")
     close(outs[1][2], dy.float()[:, :Co].sum(0), name="ring bias grad vs torch")
+
+
+@pytest.mark.parametrize("case", [
+    # Ci, Co, B, T, H, W   -- (1,3,3) stride-1 pad-1 convs, the shapes pp_wgrad's sliding-window kernel takes
+    (64, 144, 2, 3, 20, 22),      # one channel block, one 144-row block; frame and image borders inside a step
+    (128, 288, 2, 2, 14, 13),     # two channel blocks x two row blocks, odd width
+    (64, 128, 1, 5, 9, 56),       # 128-row block (8 tiles), the layer-1 width
+    (192, 230, 1, 2, 7, 7),       # ragged rows of dW (230 of 240), three channel blocks, tiny image (window >> image)
+])
+def test_sliding_window_wgrad_matches_generic(case):
+    """Sliding-window weight gradient (X window in LDS, taps = row-shifted views + border masks) against the generic
+    gather kernel and against torch's conv3d weight gradient."""
+    Ci, Co, B, T, Hh, W = case
+    k, s, p = (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    g = torch.Generator().manual_seed(5 * Ci + Co + W)
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    xf = rb(torch.randn(B, Ci, T, Hh, W, generator=g))
+    dyf = rb(torch.randn(B, Co, T, Hh, W, generator=g))
+    x, dy = to_cl(xf, geom.in_cstride), to_cl(dyf, geom.out_cstride)
+    outs = []
+    try:
+        for sw in (0, 1):
+            H.set_option("sw_wgrad", sw)
+            gw = L.conv_wgrad_raw(x, dy, geom)
+            torch.cuda.synchronize()
+            outs.append(gw.clone())
+    finally:
+        H.set_option("sw_wgrad", H.SW_WGRAD_DEFAULT)
+    scale = outs[0].abs().max().item()
+    err = (outs[0] - outs[1]).abs().max().item()
+    assert err <= 2e-5 * scale + 1e-6, f"sliding-window wgrad differs from the generic kernel by {err} (scale {scale})"
+    w = torch.zeros(Co, Ci, *k, requires_grad=True)
+    F.conv3d(xf, w, stride=s, padding=p).backward(dyf)
+    dw = torch.empty(Co, Ci, *k, dtype=torch.float32, device=DEV)
+    H.unprep_conv_grad(outs[1], dw, geom.Co, geom.Cig, geom.taps, geom.cg_in)
+    close(dw, w.grad, name="sliding-window wgrad vs torch")
