@@ -17,6 +17,7 @@
 
 int pp_opt_xcd_remap_igemm = 1;
 int pp_opt_persistent = 1;
+int pp_opt_win_igemm = 1024;   // window kernel for (1,3,3) stride-1 convs (forward / data gradient) once M >= this (0 = never)
 int pp_opt_sw_wgrad = 4096;    // sliding-window weight gradient for (1,3,3) stride-1 convs once M >= this (0 = never)
 int pp_opt_ring_wgrad = 0;      // LDS-DMA ring weight gradient once the reduce dimension has this many rows (0 = never)
 int pp_opt_ring = 192; // LDS-DMA ring variant once there are this many 256-row tiles (0 = never)
@@ -24,6 +25,7 @@ int pp_opt_xcd_remap_wgrad = 1;
 extern "C" int pp_set_option(const char* name, int value) {
   if (!name) return PP_ERR_INVALID;
   if (!strcmp(name, "xcd_remap_igemm")) { pp_opt_xcd_remap_igemm = value; return PP_OK; }
+  if (!strcmp(name, "win_igemm")) { pp_opt_win_igemm = value; return PP_OK; }
   if (!strcmp(name, "sw_wgrad")) { pp_opt_sw_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_wgrad")) { pp_opt_ring_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_igemm")) { pp_opt_ring = value; return PP_OK; }
@@ -32,6 +34,8 @@ extern "C" int pp_set_option(const char* name, int value) {
   pp_set_error("pp_set_option: unknown option %s", name);
   return PP_ERR_INVALID;
 }
+
+int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s);
 
 namespace {
 
@@ -700,6 +704,10 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   }
   PP_CHECK_ARG((long long)d.b_rows * d.ldb < 0x7ffffff0LL, "pp_igemm: Bt has >= 2^31 elements");
   hipStream_t s = (hipStream_t)stream;
+  if (pp_opt_win_igemm && (long long)d.M >= pp_opt_win_igemm) {   // (1,3,3) stride-1 convs: A window in LDS
+    const int rc_win = pp_igemm_win_try(d, s);
+    if (rc_win != 1) return rc_win;
+  }
   const int n16 = (d.N + 15) / 16;
   const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
   if (pp_opt_ring && !d.c_fp32 && d.nbatch == 1 && n16 > 4 && d.K >= 2 * BK && (!full || d.g.mode == PP_DENSE)) {

@@ -1,0 +1,438 @@
+// Window implicit GEMM for the (1,3,3) stride-1 "spatial" convolutions (forward and data gradient), gfx950.
+//
+//   C[m, n] = sum_{tap, c} A[m + off(tap), c] * Bt[n, tap, c]        off = +-((dh-1) * W + (dw-1)), zero outside the image
+//
+// igemm.hip gathers the nine shifted copies of A from global memory, one 64-deep K-step at a time: at layer-1 sizes
+// that is nine times the load instructions / L2 traffic the data needs, and the kernel runs at a fifth of the matrix
+// peak.  Here a 256-row tile keeps its rows PLUS a halo of W + 1 rows on either side in LDS (one 48- or 64-channel
+// chunk at a time, double buffered) and every tap is an address offset into that window:
+//   * the window of the next (tile, chunk) arrives by LDS-DMA, one 1-KiB piece per K-step, behind the weight slices;
+//   * the weights stream through the same three-slot ring as igemm.hip's ring kernel (K order inside a chunk is
+//     (tap, channel), flat, so 48-channel chunks -- 144, 240, 288 ... channels -- lose only the last half K-step);
+//   * taps that fall outside the image read a zero row instead (per-row 9-bit masks, computed once per tile);
+//   * counted vmcnt waits across raw barriers: each iteration waits for everything but the batch it issued last.
+// Same bf16 results as igemm.hip (same products, fp32 accumulation in a different order).
+// Replaces torchvision Conv2Plus1D's spatial Conv3d forward / input gradient (pig/models.py:113-154 call site).
+#include "common.h"
+#include <type_traits>
+
+extern int pp_opt_xcd_remap_igemm;
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int NW = 8, NT = 64 * NW, BM = 32 * NW;
+constexpr int HALO = 64;                      // rows kept on either side of the tile (>= W + 1)
+constexpr int WROWS = BM + 2 * HALO;
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) buffer_rsrc;
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void lds_dma16(const buffer_rsrc rs, unsigned char* dst, const unsigned off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, off, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uniform (0..4 here)
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+struct WinGeom {
+  FastDiv dW_, dH_;
+  int W, H;
+  int M;         // rows of A and of C (N * T * H * W)
+  int cstride;   // A row stride (elements)
+  int cg;        // A channels per tap (= K / 9)
+  int sign;      // +1 forward, -1 data gradient (source = m - off)
+};
+
+struct WinArgs {
+  const bfraw* A;
+  const bfraw* Bt;
+  bfraw* C;
+  const bfraw* residual;
+  float* colstats;
+  int N, b_rows, ldb, ldc, ldr, ldstat;
+};
+
+template <int WN, int CC, bool RES>
+__global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
+                                                          const int ntiles, const int xcd_remap) {
+  constexpr int BN = 16 * WN;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int XS = CC == 64 ? 128 : CC * 2 + 16;            // window row stride; 128-byte rows are XOR-swizzled
+  constexpr int WIN_BYTES = WROWS * XS;
+  constexpr int WPIECES = WIN_BYTES / 1024;
+  static_assert(WIN_BYTES % 1024 == 0, "window = whole DMA pieces");
+  constexpr int NWP = (WPIECES + NW - 1) / NW;                // window pieces per wave and phase
+  constexpr int NBI = (BN * 8 + NT - 1) / NT;                 // weight pieces per wave and K-step (last one maybe absent)
+  constexpr int KC = 9 * CC;                                  // flat K of one channel chunk: (tap, channel)
+  constexpr int NKC = (KC + BK - 1) / BK;                     // K-steps per chunk
+  static_assert(NKC >= NWP, "one window piece per K-step must cover a phase");
+  constexpr int STG_STRIDE = BN * 2 + 16;
+  constexpr int STG_BYTES = NW * 16 * STG_STRIDE;
+  constexpr int STAT_BYTES = NW * BN * 2 * 4;
+  static_assert(STG_BYTES <= WIN_BYTES && STAT_BYTES <= B_BYTES, "the epilogue stages in a window buffer / weight slot");
+  constexpr int SMEM = 2 * WIN_BYTES + 3 * B_BYTES + 256 + 64;
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];   // one LDS object (see igemm.hip)
+  unsigned char* const bring = smem + 2 * WIN_BYTES;
+  unsigned char* const zrow = smem + 2 * WIN_BYTES + 3 * B_BYTES;      // 256 zero bytes
+  int* const lut = (int*)(zrow + 256);                                 // row offset of each tap
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int G = gridDim.x, bid = blockIdx.x;
+  auto tile_index = [&](int it) __attribute__((always_inline)) -> int {   // persistent walk, XCD-contiguous (igemm.hip)
+    const int base = it * G;
+    const int cnt = ntiles - base < G ? ntiles - base : G;
+    if (bid >= cnt) return -1;
+    const int xq = cnt >> 3, xr = cnt & 7, xcd = bid & 7;
+    const int t = (xcd_remap && cnt >= 8) ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3) : bid;
+    return base + t;
+  };
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bt, (short)0, (int)OOB, 0x00020000);
+  const int nchunk = g.cg / CC;
+
+  if (tid < 64) ((unsigned*)zrow)[tid] = 0u;
+  if (tid < 9) lut[tid] = g.sign * ((tid / 3 - 1) * g.W + (tid % 3 - 1));
+  __syncthreads();
+
+  // ---- window DMA: piece q = wave + 8 k lands 1 KiB lane-linear; this lane's (window row, source byte column) -------
+  int w_row[NWP];
+  unsigned w_col[NWP];
+#pragma unroll
+  for (int k = 0; k < NWP; ++k) {
+    const int q = wave + NW * k;
+    if (CC == 64) {
+      w_row[k] = q * 8 + (lane >> 3);
+      w_col[k] = (unsigned)(((lane & 7) ^ swz(w_row[k])) * 16);   // slot (lane & 7) holds chunk slot ^ swz(row)
+    } else {
+      const int o = q * 1024 + lane * 16;
+      w_row[k] = o / XS;
+      const int cb = o % XS;
+      w_col[k] = cb < CC * 2 ? (unsigned)cb : OOB;
+    }
+  }
+  auto dma_window_piece = [&](const int k, unsigned char* wbuf, const int m0, const int chunk) __attribute__((always_inline)) {
+    const int q = wave + NW * k;
+    if (q < WPIECES) {
+      const int srow = m0 - HALO + w_row[k];
+      const bool ok = (w_col[k] != OOB) & ((unsigned)srow < (unsigned)g.M);
+      lds_dma16(rsA, wbuf + q * 1024, ok ? (unsigned)(srow * g.cstride + chunk * CC) * 2u + w_col[k] : OOB);
+    }
+  };
+  // ---- weight DMA: as igemm.hip's ring (rows (tid >> 3) + 64 i, slot tid & 7 holds K chunk (tid & 7) ^ swz(row)) ------
+  const int kqB = (tid & 7) ^ swz(tid >> 3);
+  const bool b_last = 8 * wave + 64 * (NBI - 1) < BN;   // does this wave own a piece in the last weight pass
+  const int nB = b_last ? NBI : NBI - 1;
+  unsigned bbase[NBI];
+  int tapB = 0, cB = 0, chunkB = 0, jB = 0;             // cursor of the next weight K-step to issue (inside the tile)
+  auto reset_b_cursor = [&]() __attribute__((always_inline)) {
+    const int kf = kqB * 8;
+    tapB = kf >= CC ? 1 : 0;
+    cB = kf - tapB * CC;
+    chunkB = 0;
+    jB = 0;
+  };
+  auto dma_weights = [&](unsigned char* slot) __attribute__((always_inline)) {   // issue the cursor's K-step, advance
+    const bool k_ok = tapB < 9;
+    const unsigned koff = (unsigned)(tapB * g.cg + chunkB * CC + cB) * 2u;
+    unsigned char* dst = slot + (8 * wave) * 128;
+#pragma unroll
+    for (int i = 0; i < NBI; ++i)
+      if (i < NBI - 1 || b_last) lds_dma16(rsB, dst + 64 * i * 128, (k_ok & (bbase[i] != OOB)) ? bbase[i] + koff : OOB);
+    cB += BK;
+    while (cB >= CC) { cB -= CC; ++tapB; }
+    if (++jB == NKC) {
+      jB = 0;
+      ++chunkB;
+      const int kf = kqB * 8;
+      tapB = kf >= CC ? 1 : 0;
+      cB = kf - tapB * CC;
+    }
+  };
+
+  // ---- per-tile state -------------------------------------------------------------------------------------------
+  int mb = 0, nb = 0;
+  unsigned vmask[2];     // bit t: tap t of fragment row (wave * 32 + mt * 16 + fr) lies inside the image
+  auto setup_tile = [&](const int tile) __attribute__((always_inline)) {
+    nb = tile % nblk_n;
+    mb = tile / nblk_n;
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+      const int brow = (tid >> 3) + 64 * i;
+      const int n = nb * BN + brow;
+      bbase[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : OOB;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = mb * BM + wave * 32 + mt * 16 + fr;
+      const uint32_t q1 = fdiv((uint32_t)m, g.dW_);
+      const int w = m - (int)q1 * g.W;
+      const int h = (int)q1 - (int)fdiv(q1, g.dH_) * g.H;
+      unsigned v = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int sh = g.sign * (t / 3 - 1), sw = g.sign * (t % 3 - 1);
+        v |= (unsigned)(((unsigned)(h + sh) < (unsigned)g.H) & ((unsigned)(w + sw) < (unsigned)g.W)) << t;
+      }
+      vmask[mt] = m < g.M ? v : 0u;
+    }
+  };
+
+  f32x4 acc[2][WN];
+  // one 64-deep K-step of chunk-flat K: lane's two k-octets (ks * 4 + fq) have their own (tap, channel)
+  int tapA[2], cA[2];
+  auto reset_a_cursor = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kf = (ks * 4 + fq) * 8;
+      tapA[ks] = kf >= CC ? 1 : 0;
+      cA[ks] = kf - tapA[ks] * CC;
+    }
+  };
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
+  const unsigned zaddr = lds0 + (unsigned)(2 * WIN_BYTES + 3 * B_BYTES) + (unsigned)(fr * 16);
+  auto compute = [&](const unsigned char* win, const unsigned char* bslot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int tap = tapA[ks], c = cA[ks];
+      const int roff = lut[tap < 9 ? tap : 0];
+      bf16x8 af[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int wrow = wave * 32 + mt * 16 + fr + HALO + roff;
+        const int col = CC == 64 ? (((c >> 3) ^ swz(wrow)) << 4) : c * 2;
+        const bool ok = ((vmask[mt] >> tap) & 1u) != 0u;    // (tap >= 9, the K tail, has no bit set)
+        const unsigned char* a = ok ? win + wrow * XS + col : zrow + fr * 16;
+        af[mt] = *(const bf16x8*)a;
+      }
+      const int fsw = ((ks * 4 + fq) ^ swz(fr)) << 4;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const bf16x8 bfm = *(const bf16x8*)(bslot + (j * 16 + fr) * 128 + fsw);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfm, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfm, acc[1][j], 0, 0, 0);
+      }
+      cA[ks] += BK;
+      while (cA[ks] >= CC) { cA[ks] -= CC; ++tapA[ks]; }
+    }
+  };
+
+  // ---- epilogue (plain bf16 store, optional residual add, optional BatchNorm column statistics); igemm.hip's ------
+  const int ncols_store = (p.N + 7) & ~7;
+  auto epilogue = [&](const int mb_e, const int nb_e, unsigned char* const ebuf, unsigned char* const sbuf) __attribute__((always_inline)) {
+    const int m_wave = mb_e * BM + wave * 32;
+    unsigned char* stg = ebuf + wave * 16 * STG_STRIDE;
+    unsigned char* stg_w = stg + (fq * 4) * STG_STRIDE + fr * 2;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *(bfraw*)(stg_w + r * STG_STRIDE + j * 32) = f2bf(acc[mt][j][r]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < (32 * WN + 63) / 64; ++it) {
+        const int cid = lane + 64 * it;
+        const int row = cid / (2 * WN);
+        const int ch = cid % (2 * WN);
+        const int m = m_wave + mt * 16 + row;
+        const int col = nb_e * BN + ch * 8;
+        if (cid < 32 * WN && m < g.M && col < ncols_store) {
+          u32x4 vv;   // (inline asm: a plain LDS load here makes hipcc drain the DMAs in flight, see igemm.hip)
+          const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(stg + row * STG_STRIDE + ch * 16);
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vv) : "v"(a) : "memory");
+          uint4 v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+          if (RES) {
+            const uint4 rv = *(const uint4*)(p.residual + (long long)m * p.ldr + col);
+            float x[8], y[8];
+            unpack8(v, x);
+            unpack8(rv, y);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] += y[q];
+            v = pack8(x);
+          }
+          *(uint4*)(p.C + (long long)m * p.ldc + col) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (p.colstats) {   // per-column sum / sum of squares per 128 output rows, deterministic (igemm.hip)
+      float* statbuf = (float*)sbuf;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[mt][j][r];
+            s1 += v;
+            s2 += v * v;
+          }
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16);
+        s2 += __shfl_xor(s2, 32);
+        if (fq == 0) {
+          statbuf[(wave * BN + j * 16 + fr) * 2 + 0] = s1;
+          statbuf[(wave * BN + j * 16 + fr) * 2 + 1] = s2;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int idx = tid; idx < BN * (NW / 4); idx += NT) {
+        const int c = idx % BN, h = idx / BN;
+        const int n = nb_e * BN + c;
+        const long long prow = (long long)mb_e * (NW / 4) + h;
+        if (n < p.ldstat && prow * 128 < g.M) {
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            a += statbuf[((4 * h + w) * BN + c) * 2 + 0];
+            b += statbuf[((4 * h + w) * BN + c) * 2 + 1];
+          }
+          p.colstats[(prow * 2 + 0) * p.ldstat + n] = a;
+          p.colstats[(prow * 2 + 1) * p.ldstat + n] = b;
+        }
+      }
+    }
+  };
+
+  // ---- tile loop.  Phase = (tile, chunk); its window sits in buffer (phase counter & 1).  Iteration s of a tile:
+  //   wait for every DMA except the batch issued by iteration s - 1; barrier; issue the weights of step s + 2 and one
+  //   piece of the next phase's window; multiply step s.
+  int it = 0;
+  int tile = tile_index(0);
+  if (tile < 0) return;
+  setup_tile(tile);
+  int wsel = 0;                       // window buffer of the current phase
+  int bsl = 0;                        // weight ring slot of the current K-step
+  const int S = nchunk * NKC;         // K-steps per tile
+#pragma unroll
+  for (int k = 0; k < NWP; ++k) dma_window_piece(k, smem, mb * BM, 0);
+  reset_b_cursor();
+  dma_weights(bring);
+  if (S > 1) dma_weights(bring + B_BYTES);
+  int last_batch = 0;                 // DMA instructions this wave issued in the previous iteration
+  bool drain = true;                  // first step of a tile: wait for everything (epilogue stores included)
+  while (true) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int next_tile = tile_index(it + 1);
+    const int next_m0 = next_tile >= 0 ? (next_tile / nblk_n) * BM : 0;
+    int s = 0;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      reset_a_cursor();
+      // the phase after this one: next chunk of this tile, or chunk 0 of the next tile, or nothing
+      const bool more_chunks = chunk + 1 < nchunk;
+      const bool have_next = more_chunks || next_tile >= 0;
+      const int nm0 = more_chunks ? mb * BM : next_m0;
+      const int nchunk_i = more_chunks ? chunk + 1 : 0;
+      unsigned char* const win = smem + wsel * WIN_BYTES;
+      unsigned char* const nwin = smem + (wsel ^ 1) * WIN_BYTES;
+      for (int j = 0; j < NKC; ++j, ++s) {
+        wait_vmcnt_dyn(drain ? 0 : last_batch);
+        drain = false;
+        __builtin_amdgcn_s_barrier();
+        int batch = 0;
+        if (s + 2 < S) {
+          dma_weights(bring + (bsl >= 1 ? bsl - 1 : 2) * B_BYTES);
+          batch += nB;
+        }
+        if (have_next && j < NWP) {
+          dma_window_piece(j, nwin, nm0, nchunk_i);
+          batch += (wave + NW * j < WPIECES) ? 1 : 0;
+        }
+        last_batch = batch;
+        compute(win, bring + bsl * B_BYTES);
+        bsl = bsl == 2 ? 0 : bsl + 1;
+      }
+      wsel ^= 1;
+    }
+    const int mb_done = mb, nb_done = nb;
+    unsigned char* const ebuf = smem + (wsel ^ 1) * WIN_BYTES;   // the window just consumed stages the output
+    unsigned char* const sbuf = bring + (bsl == 0 ? 2 : bsl - 1) * B_BYTES;   // ... the weight slot just consumed the statistics
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // every wave is done reading it
+    if (next_tile >= 0) {                                       // the next tile's first two weight steps fly under the epilogue
+      setup_tile(next_tile);
+      reset_b_cursor();
+      dma_weights(bring + bsl * B_BYTES);
+      if (S > 1) dma_weights(bring + (bsl == 2 ? 0 : bsl + 1) * B_BYTES);
+    }
+    epilogue(mb_done, nb_done, ebuf, sbuf);
+    if (next_tile < 0) break;
+    tile = next_tile;
+    ++it;
+    drain = true;
+  }
+}
+
+template <int WN, int CC>
+int launch_win(const pp_igemm_desc& d, hipStream_t s) {
+  constexpr int BN = 16 * WN;
+  const pp_gather& gg = d.g;
+  WinGeom g;
+  g.W = gg.Gw; g.H = gg.Gh; g.M = d.M; g.cstride = gg.cstride; g.cg = gg.cg;
+  g.sign = gg.mode == PP_CONV_FWD ? 1 : -1;
+  g.dW_ = make_fastdiv((uint32_t)gg.Gw);
+  g.dH_ = make_fastdiv((uint32_t)gg.Gh);
+  WinArgs a;
+  a.A = (const bfraw*)d.A; a.Bt = (const bfraw*)d.Bt; a.C = (bfraw*)d.C; a.residual = (const bfraw*)d.residual;
+  a.colstats = d.colstats;
+  a.N = d.N; a.b_rows = d.b_rows; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr; a.ldstat = d.ldstat;
+  const int nblk_n = (d.N + BN - 1) / BN;
+  const long long nblk_m = ((long long)d.M + BM - 1) / BM;
+  const long long ntiles = nblk_m * nblk_n;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
+  const long long gx = ntiles < 256 ? ntiles : 256;
+  dim3 grid((unsigned)gx, 1, 1), block(NT);
+  if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+  else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+}  // namespace
+
+// PP_OK if the window kernel took the problem, 1 if the shape is not one it handles (caller falls through), < 0 on error.
+// `d` has been validated by pp_igemm.
+int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
+  const pp_gather& g = d.g;
+  const bool conv = g.mode == PP_CONV_FWD || g.mode == PP_CONV_DGRAD;
+  const bool shape_ok = conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre && !d.omap &&
+                        g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 &&
+                        g.ph == 1 && g.pw == 1 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && g.Gw + 1 <= HALO &&
+                        d.K == 9 * g.cg && (g.cg % 64 == 0 || g.cg % 48 == 0) &&
+                        (long long)d.M * g.cstride < 0x7fffffffLL && (!d.residual || d.ldr % 8 == 0);
+  if (!shape_ok) return 1;
+  const int n16 = (d.N + 15) / 16;
+  // tile widths: 64 columns (narrow outputs) or 128 / 144 (whichever pads N less)
+  if (g.cg % 64 == 0) {
+    if (n16 <= 4) return launch_win<4, 64>(d, s);
+    const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
+    return c9 <= c8 ? launch_win<9, 64>(d, s) : launch_win<8, 64>(d, s);
+  }
+  if (n16 <= 4) return launch_win<4, 48>(d, s);
+  const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
+  return c9 <= c8 ? launch_win<9, 48>(d, s) : launch_win<8, 48>(d, s);
+}

@@ -57,6 +57,7 @@ def gather_conv(mode, R, G, k, s, p, cg, cstride):
 
 RING_WGRAD_DEFAULT = 0     # pp_set_option("ring_wgrad", n): LDS-DMA ring weight gradient once M >= n rows (0 = never)
 SW_WGRAD_DEFAULT = 4096   # pp_set_option("sw_wgrad", n): sliding-window wgrad of (1,3,3) stride-1 convs once M >= n (0 = never)
+WIN_IGEMM_DEFAULT = 1024   # pp_set_option("win_igemm", n): window conv kernel for (1,3,3) stride-1 convs once M >= n (0 = never)
 RING_IGEMM_DEFAULT = 192   # pp_set_option("ring_igemm", n): LDS-DMA ring GEMM once there are n 256-row tiles (0 = never)
 
 

@@ -694,3 +694,46 @@ def test_sliding_window_wgrad_matches_generic(case):
     dw = torch.empty(Co, Ci, *k, dtype=torch.float32, device=DEV)
     H.unprep_conv_grad(outs[1], dw, geom.Co, geom.Cig, geom.taps, geom.cg_in)
     close(dw, w.grad, name="sliding-window wgrad vs torch")
+
+
+@pytest.mark.parametrize("case", [
+    # Ci, Co, B, T, H, W  -- (1,3,3) stride-1 pad-1 convs: forward Ci -> Co and data gradient Co -> Ci
+    (64, 144, 2, 3, 20, 22),      # fwd: one 64-channel chunk, 144 columns; dgrad: three 48-channel chunks, 64 columns
+    (128, 288, 1, 2, 28, 28),     # fwd: two chunks, two column blocks; dgrad: six 48-channel chunks, 128 columns
+    (64, 230, 1, 3, 9, 56),       # dgrad from 240 padded channels (five 48-channel chunks); layer-1 width
+    (256, 576, 1, 1, 14, 14),     # dgrad with 64-channel chunks (576 = 9 x 64); window >> image
+    (64, 128, 3, 1, 7, 5),        # tiny images: most of every window lies in neighbouring images; ragged last tile
+])
+def test_window_igemm_matches_gather_igemm(case):
+    """Window conv kernel (A halo window in LDS, taps = address offsets, zero row outside the image) against the
+    gather kernel: forward with BatchNorm statistics, data gradient with and without the fused residual add."""
+    Ci, Co, B, T, Hh, W = case
+    k, s, p = (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    g = torch.Generator().manual_seed(3 * Ci + Co + Hh)
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    x = torch.randn(geom.Min, geom.in_cstride, generator=g).to(torch.bfloat16).to(DEV)
+    x[:, Ci:] = 0
+    dy = torch.randn(geom.M, geom.out_cstride, generator=g).to(torch.bfloat16).to(DEV)
+    dy[:, Co:] = 0
+    res = torch.randn(geom.Min, geom.in_cstride, generator=g).to(torch.bfloat16).to(DEV)
+    w = torch.randn(Co, Ci, *k, generator=g).to(DEV) / math.sqrt(Ci * 9)
+    wf, wd = L.prep_conv_weights(w, geom)
+    outs = []
+    try:
+        for win in (0, 1):
+            H.set_option("win_igemm", win)
+            y, st = L.conv_fwd(x, geom, wf, stats=True)
+            dx = L.conv_dgrad(dy, geom, wd)
+            dxr = L.conv_dgrad(dy, geom, wd, residual=res)
+            torch.cuda.synchronize()
+            outs.append((y.float(), st.clone(), dx.float(), dxr.float()))
+    finally:
+        H.set_option("win_igemm", H.WIN_IGEMM_DEFAULT)
+    for a, b, name in zip(outs[0], outs[1], ("fwd", "colstats", "dgrad", "dgrad + residual")):
+        assert a.shape == b.shape, name
+        scale = a.abs().max().item()
+        err = (a - b).abs().max().item()
+        # same products, fp32 sums in a different order: at most one bf16 rounding step apart (stats: fp32 sums)
+        tol = (2e-4 if name == "colstats" else 2.0 ** -7) * scale
+        assert err <= tol, f"{name}: window kernel differs by {err} (scale {scale})"
+        assert (a - b).abs().mean().item() <= 1e-3 * scale, name
