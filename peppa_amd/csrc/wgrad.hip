@@ -15,6 +15,7 @@ extern int pp_opt_xcd_remap_wgrad;
 extern int pp_opt_ring_wgrad;
 extern int pp_opt_sw_wgrad;
 int pp_wgrad_sw_try(const pp_wgrad_desc& d, hipStream_t s);
+int pp_wgrad_tw_try(const pp_wgrad_desc& d, hipStream_t s, bool force);
 
 namespace {
 
@@ -704,9 +705,11 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
                  "pp_wgrad: gathered tensor >= 2^31 elements or M not a multiple of Rt*Rh*Rw");
   }
   hipStream_t s = (hipStream_t)stream;
-  if (pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad) {   // (1,3,3) stride-1 convs: sliding-window kernel
+  if (pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad) {   // (1,3,3) stride-1 convs: window along m
     const int rc_sw = pp_wgrad_sw_try(d, s);
     if (rc_sw != 1) return rc_sw;
+    const int rc_tw = pp_wgrad_tw_try(d, s, pp_opt_sw_wgrad == 1);                    // (3,1,1) stride-1 convs: window over time
+    if (rc_tw != 1) return rc_tw;
   }
   const int n16 = (d.Ni + 15) / 16;
   if (pp_opt_ring_wgrad && d.nbatch == 1 && n16 > 4 && (long long)d.M >= pp_opt_ring_wgrad) {

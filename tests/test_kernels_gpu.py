@@ -737,3 +737,39 @@ def test_window_igemm_matches_gather_igemm(case):
         tol = (2e-4 if name == "colstats" else 2.0 ** -7) * scale
         assert err <= tol, f"{name}: window kernel differs by {err} (scale {scale})"
         assert (a - b).abs().mean().item() <= 1e-3 * scale, name
+
+
+@pytest.mark.parametrize("case", [
+    # Ci, Co, B, T, H, W  -- (3,1,1) stride-1 pad-(1,0,0) convs, the shapes pp_wgrad's temporal window kernel takes
+    (144, 64, 2, 5, 8, 8),        # one 144-channel block, 64 rows of dW; frames of exactly 64 positions
+    (288, 128, 1, 4, 9, 10),      # two channel blocks, ragged 64-position blocks (90 positions per frame)
+    (230, 128, 2, 3, 5, 5),       # 240 padded channels: second channel block partly empty; frames smaller than a block
+    (576, 256, 1, 2, 7, 7),       # two row blocks of dW, T = 2 (every step has a tap outside the clip)
+])
+def test_temporal_window_wgrad_matches_generic(case):
+    """Temporal sliding-window weight gradient (X blocks of frames t-1, t, t+1 kept in an LDS ring while a 64-position
+    column is walked through time) against the generic gather kernel and torch's conv3d weight gradient."""
+    Ci, Co, B, T, Hh, W = case
+    k, s, p = (3, 1, 1), (1, 1, 1), (1, 0, 0)
+    g = torch.Generator().manual_seed(7 * Ci + Co + T)
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    xf = rb(torch.randn(B, Ci, T, Hh, W, generator=g))
+    dyf = rb(torch.randn(B, Co, T, Hh, W, generator=g))
+    x, dy = to_cl(xf, geom.in_cstride), to_cl(dyf, geom.out_cstride)
+    outs = []
+    try:
+        for sw in (0, 1):
+            H.set_option("sw_wgrad", sw)
+            gw = L.conv_wgrad_raw(x, dy, geom)
+            torch.cuda.synchronize()
+            outs.append(gw.clone())
+    finally:
+        H.set_option("sw_wgrad", H.SW_WGRAD_DEFAULT)
+    scale = outs[0].abs().max().item()
+    err = (outs[0] - outs[1]).abs().max().item()
+    assert err <= 2e-5 * scale + 1e-6, f"temporal window wgrad differs from the generic kernel by {err} (scale {scale})"
+    w = torch.zeros(Co, Ci, *k, requires_grad=True)
+    F.conv3d(xf, w, stride=s, padding=p).backward(dyf)
+    dw = torch.empty(Co, Ci, *k, dtype=torch.float32, device=DEV)
+    H.unprep_conv_grad(outs[1], dw, geom.Co, geom.Cig, geom.taps, geom.cg_in)
+    close(dw, w.grad, name="temporal window wgrad vs torch")
