@@ -114,26 +114,50 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
+// Streaming passes: a thread keeps ONE 8-channel chunk (its per-channel parameters live in registers for the whole
+// launch) and walks rows; 256 / cpr rows are covered per block pass, so a pass reads one contiguous span.  Two rows
+// are in flight per thread and iteration.
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&f)[8]) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bfraw* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const bfraw* __restrict__ res,
-                                                       int relu, bfraw* __restrict__ z, long long nchunks, int cpr) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % cpr) * 8;
+                                                       int relu, bfraw* __restrict__ z, long long M, int cpr) {
+  const int rpb = 256 / cpr;
+  const int tid = threadIdx.x;
+  if (tid >= rpb * cpr) return;
+  const int ch = tid % cpr, rsub = tid / cpr;
+  float sc[8], sh[8];
+  load8(scale + ch * 8, sc);
+  load8(shift + ch * 8, sh);
+  auto one = [&](const uint4 v, const uint4 rv) __attribute__((always_inline)) -> uint4 {
     float f[8], r[8];
-    unpack8(*(const uint4*)(y + i * 8), f);
-    const float4 s0 = *(const float4*)(scale + c), s1 = *(const float4*)(scale + c + 4);
-    const float4 h0 = *(const float4*)(shift + c), h1 = *(const float4*)(shift + c + 4);
-    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    if (res) unpack8(*(const uint4*)(res + i * 8), r);
+    unpack8(v, f);
+    if (res) unpack8(rv, r);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = f[q] * sc[q] + sh[q];
-      if (res) v += r[q];
-      if (relu) v = fmaxf(v, 0.f);
-      f[q] = v;
+      float t = f[q] * sc[q] + sh[q];
+      if (res) t += r[q];
+      if (relu) t = fmaxf(t, 0.f);
+      f[q] = t;
     }
-    *(uint4*)(z + i * 8) = pack8(f);
+    return pack8(f);
+  };
+  const long long stride = (long long)gridDim.x * rpb;
+  long long r = (long long)blockIdx.x * rpb + rsub;
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  for (; r + stride < M; r += 2 * stride) {
+    const long long i0 = (r * cpr + ch) * 8, i1 = ((r + stride) * cpr + ch) * 8;
+    const uint4 v0 = *(const uint4*)(y + i0), v1 = *(const uint4*)(y + i1);
+    const uint4 r0 = res ? *(const uint4*)(res + i0) : zero4, r1 = res ? *(const uint4*)(res + i1) : zero4;
+    *(uint4*)(z + i0) = one(v0, r0);
+    *(uint4*)(z + i1) = one(v1, r1);
+  }
+  if (r < M) {
+    const long long i0 = (r * cpr + ch) * 8;
+    *(uint4*)(z + i0) = one(*(const uint4*)(y + i0), res ? *(const uint4*)(res + i0) : zero4);
   }
 }
 
@@ -142,6 +166,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bfraw* __restr
                                                             const float* __restrict__ rstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu, long long M, int Cp,
                                                             int rows_per_blk, float* partials) {
+  const int my_ch = threadIdx.x % (Cp >> 3);   // col_reduce gives this thread the same chunk on every row
+  float mu[8], rs[8], sc[8], sh[8];
+  load8(mean + my_ch * 8, mu);
+  load8(rstd + my_ch * 8, rs);
+  if (relu && !z) { load8(scale + my_ch * 8, sc); load8(shift + my_ch * 8, sh); }
   col_reduce<2>(M, Cp, rows_per_blk, partials, [&](long long r, int ch, float (*acc)[8]) {
     const long long o = r * Cp + ch * 8;
     float d[8], yy[8], zz[8];
@@ -151,13 +180,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bfraw* __restr
       if (z) unpack8(*(const uint4*)(z + o), zz);
       else  // no residual: the ReLU mask is recomputed from y instead of reading z (one stream less)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) zz[q] = yy[q] * scale[ch * 8 + q] + shift[ch * 8 + q];
+        for (int q = 0; q < 8; ++q) zz[q] = yy[q] * sc[q] + sh[q];
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int c = ch * 8 + q;
       const float g = (relu && !(zz[q] > 0.f)) ? 0.f : d[q];
-      const float xh = (yy[q] - mean[c]) * rstd[c];
+      const float xh = (yy[q] - mu[q]) * rs[q];
       acc[0][q] += g;
       acc[1][q] += g * xh;
     }
@@ -198,28 +226,52 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bfraw* __restri
                                                            const float* __restrict__ rstd, const float* __restrict__ coef,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int relu, bfraw* __restrict__ dy, bfraw* __restrict__ dres,
-                                                           long long nchunks, int cpr, int Cp) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
-    const int c0 = (int)(i % cpr) * 8;
+                                                           long long M, int cpr, int Cp) {
+  const int rpb = 256 / cpr;
+  const int tid = threadIdx.x;
+  if (tid >= rpb * cpr) return;
+  const int ch = tid % cpr, rsub = tid / cpr;
+  float mu[8], rs[8], k0[8], k1[8], k2[8], sc[8], sh[8];
+  load8(mean + ch * 8, mu);
+  load8(rstd + ch * 8, rs);
+  load8(coef + ch * 8, k0);
+  load8(coef + Cp + ch * 8, k1);
+  load8(coef + 2 * Cp + ch * 8, k2);
+  if (relu && !z) { load8(scale + ch * 8, sc); load8(shift + ch * 8, sh); }
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  auto one = [&](const long long i, const uint4 vd, const uint4 vy, const uint4 vz) __attribute__((always_inline)) {
     float d[8], yy[8], zz[8], o[8];
-    unpack8(*(const uint4*)(dz + i * 8), d);
-    unpack8(*(const uint4*)(y + i * 8), yy);
+    unpack8(vd, d);
+    unpack8(vy, yy);
     if (relu) {
-      if (z) unpack8(*(const uint4*)(z + i * 8), zz);
+      if (z) unpack8(vz, zz);
       else
 #pragma unroll
-        for (int q = 0; q < 8; ++q) zz[q] = yy[q] * scale[c0 + q] + shift[c0 + q];
+        for (int q = 0; q < 8; ++q) zz[q] = yy[q] * sc[q] + sh[q];
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int c = c0 + q;
       const float g = (relu && !(zz[q] > 0.f)) ? 0.f : d[q];
-      const float xh = (yy[q] - mean[c]) * rstd[c];
-      o[q] = coef[c] * (g - coef[Cp + c] - xh * coef[2 * Cp + c]);
+      const float xh = (yy[q] - mu[q]) * rs[q];
+      o[q] = k0[q] * (g - k1[q] - xh * k2[q]);
       d[q] = g;
     }
-    *(uint4*)(dy + i * 8) = pack8(o);
-    if (dres) *(uint4*)(dres + i * 8) = pack8(d);
+    *(uint4*)(dy + i) = pack8(o);
+    if (dres) *(uint4*)(dres + i) = pack8(d);
+  };
+  const long long stride = (long long)gridDim.x * rpb;
+  long long r = (long long)blockIdx.x * rpb + rsub;
+  for (; r + stride < M; r += 2 * stride) {
+    const long long i0 = (r * cpr + ch) * 8, i1 = ((r + stride) * cpr + ch) * 8;
+    const uint4 d0 = *(const uint4*)(dz + i0), d1 = *(const uint4*)(dz + i1);
+    const uint4 y0 = *(const uint4*)(y + i0), y1 = *(const uint4*)(y + i1);
+    const uint4 z0 = (relu && z) ? *(const uint4*)(z + i0) : zero4, z1 = (relu && z) ? *(const uint4*)(z + i1) : zero4;
+    one(i0, d0, y0, z0);
+    one(i1, d1, y1, z1);
+  }
+  if (r < M) {
+    const long long i0 = (r * cpr + ch) * 8;
+    one(i0, *(const uint4*)(dz + i0), *(const uint4*)(y + i0), (relu && z) ? *(const uint4*)(z + i0) : zero4);
   }
 }
 
@@ -281,8 +333,8 @@ extern "C" int pp_bn_apply(const void* y, const float* scale, const float* shift
                            long long M, int Cp, pp_stream_t s) {
   CHECK_CP(Cp, "pp_bn_apply");
   const long long nchunks = M * (Cp / 8);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nchunks)), dim3(256), 0, (hipStream_t)s, (const bfraw*)y, scale,
-                     shift, (const bfraw*)res, relu, (bfraw*)z, nchunks, Cp / 8);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const bfraw*)y, scale,
+                     shift, (const bfraw*)res, relu, (bfraw*)z, M, Cp / 8);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -314,8 +366,8 @@ extern "C" int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, con
   PP_CHECK_ARG(!relu || z || (scale && shift), "pp_bn_bwd_apply: relu needs z or scale/shift");
   CHECK_CP(Cp, "pp_bn_bwd_apply");
   const long long nchunks = M * (Cp / 8);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nchunks)), dim3(256), 0, (hipStream_t)s, (const bfraw*)dz,
-                     (const bfraw*)y, (const bfraw*)z, mean, rstd, coef, scale, shift, relu, (bfraw*)dy, (bfraw*)dres, nchunks, Cp / 8, Cp);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const bfraw*)dz,
+                     (const bfraw*)y, (const bfraw*)z, mean, rstd, coef, scale, shift, relu, (bfraw*)dy, (bfraw*)dres, M, Cp / 8, Cp);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -64,7 +64,7 @@ RING_IGEMM_DEFAULT = 192   # pp_set_option("ring_igemm", n): LDS-DMA ring GEMM o
 # ---- optional in-process kernel timing (bench.py roofline): HIP events on the launch stream ----------
 PROFILE_ON = False
 PROFILE = {}
-PROFILE_MIN_FLOP = 2.0e10
+PROFILE_MIN_FLOP = 1.5e11   # only the big launches are timed: every timed launch costs two event records on its stream
 _MODE_NAMES = {DENSE: "dense", CONV_FWD: "conv_fwd", CONV_DGRAD: "conv_dgrad"}
 
 
@@ -97,6 +97,24 @@ def profile_summary(key=None):
     return best
 
 
+def _spatial_s1(g):
+    return (g.mode != DENSE and (g.kt, g.kh, g.kw) == (1, 3, 3) and (g.st, g.sh, g.sw) == (1, 1, 1)
+            and (g.Gt, g.Gh, g.Gw) == (g.Rt, g.Rh, g.Rw))
+
+
+def _igemm_family(g):
+    """Kernel family pp_igemm dispatches to with the default options (names as rocprofv3 prints them)."""
+    return "igemm_win_kernel" if _spatial_s1(g) and (g.cg % 64 == 0 or g.cg % 48 == 0) else "igemm_kernel"
+
+
+def _wgrad_family(g):
+    if g.mode == CONV_FWD and _spatial_s1(g) and g.cg % 64 == 0:
+        return "wgrad_sw_kernel"
+    if g.mode == CONV_FWD and (g.kt, g.kh, g.kw) == (3, 1, 1) and (g.st, g.sh, g.sw) == (1, 1, 1) and g.cg >= 96:
+        return "wgrad_tw_kernel"
+    return "wgrad_kernel"
+
+
 def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NONE, residual=None, ldr=0,
           Cpre=None, colstats=None, ldstat=0, nbatch=1, inner=1, a_s=(0, 0), b_s=(0, 0), c_s=(0, 0),
           bias_s=(0, 0), omap=None):
@@ -116,7 +134,7 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
     if omap is not None:  # ((Ot, Oh, Ow), (scale t,h,w), (offset t,h,w))
         d.omap = 1
         (d.Ot, d.Oh, d.Ow), (d.os_t, d.os_h, d.os_w), (d.oo_t, d.oo_h, d.oo_w) = omap
-    _profiled(f"igemm_kernel<{_MODE_NAMES[g.mode]}> N={N} K={K}", 2.0 * M * N * K * nbatch,
+    _profiled(f"{_igemm_family(g)}<{_MODE_NAMES[g.mode]}> N={N} K={K}", 2.0 * M * N * K * nbatch,
               lambda: call("pp_igemm", C.byref(d), _s()))
 
 
@@ -126,7 +144,7 @@ def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=
     d.X, d.dY, d.ldy, d.dW, d.ldw = _p(X, bf16), _p(dY, bf16), ldy, _p(dW, f32), ldw
     d.msplit, d.nbatch, d.x_s, d.dy_s, d.dw_s = msplit, nbatch, x_s, dy_s, dw_s
     d.dbias, d.dbias_s = _p(dbias, f32), dbias_s
-    _profiled(f"wgrad_kernel<{_MODE_NAMES[g.mode]}> Ni={Ni} Kj={Kj}", 2.0 * M * Ni * Kj * nbatch,
+    _profiled(f"{_wgrad_family(g)}<{_MODE_NAMES[g.mode]}> Ni={Ni} Kj={Kj}", 2.0 * M * Ni * Kj * nbatch,
               lambda: call("pp_wgrad", C.byref(d), _s()))
 
 
