@@ -69,10 +69,11 @@ _MODE_NAMES = {DENSE: "dense", CONV_FWD: "conv_fwd", CONV_DGRAD: "conv_dgrad"}
 
 
 PROFILE_STREAM = None  # only launches on this stream are timed (the video trunk's stream in bench.py)
+PROFILE_ONLY = None    # if set: only this kernel family is timed (bench.py picks it during warm-up)
 
 
 def _profiled(key, flops, fn):
-    if not PROFILE_ON or flops < PROFILE_MIN_FLOP:
+    if not PROFILE_ON or flops < PROFILE_MIN_FLOP or (PROFILE_ONLY is not None and key != PROFILE_ONLY):
         return fn()
     if PROFILE_STREAM is not None and torch.cuda.current_stream() != PROFILE_STREAM:
         return fn()
