@@ -166,9 +166,10 @@ int pp_colsum_bf16(const void* x, long long M, int N, int ld, float* out, pp_str
 /* ---- LayerNorm over the last dim (torchaudio wav2vec2 components) ---------------------- */
 int pp_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
                      float* rstd, int rows, int D, pp_stream_t s);
-/* dgamma/dbeta are accumulated (+=) with atomics; zero them first */
+/* dgamma/dbeta are accumulated (+=); zero them first.  ws = optional scratch [ws_blocks][2][D] fp32: per-workgroup
+ * partials + a second pass (deterministic, no same-address atomics); NULL -> atomics */
 int pp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                     void* dx, float* dgamma, float* dbeta, int rows, int D, pp_stream_t s);
+                     void* dx, float* dgamma, float* dbeta, int rows, int D, float* ws, int ws_blocks, pp_stream_t s);
 
 /* ---- softmax over attention scores (SelfAttention in wav2vec2) ------------------------- */
 /* S fp32 [nb][T][lds] -> P bf16 [nb][T][ldp], P = softmax(scale*S) over T cols, pad cols = 0 */
@@ -204,6 +205,11 @@ int pp_weightnorm_bwd(const float* dwt, const float* v, const float* g, const fl
 /* spatial mean: x bf16 [B][T][HW][Cp] -> out fp32 [B][T][C] */
 int pp_spatial_mean_fwd(const void* x, float* out, int B, int T, int HW, int C, int Cp, pp_stream_t s);
 int pp_spatial_mean_bwd(const float* dout, void* dx, int B, int T, int HW, int C, int Cp, pp_stream_t s);
+/* pig/models.py:45-51 AveragePool = nn.AdaptiveAvgPool2d((S, 1)) on the 3-D (B, T, F) tensor (read by torch as (C, H, W)):
+ * out[b][i] = mean over t in [floor(i T / S), ceil((i + 1) T / S)) and over ALL f of x[b][t][f]; fp32. */
+int pp_avgpool_tf_fwd(const float* x, int B, int T, int F, int S, float* out, pp_stream_t s);
+int pp_avgpool_tf_bwd(const float* dout, int B, int T, int F, int S, float* dx, pp_stream_t s);
+
 /* attention pooling over time + Linear projection + L2 normalise (F.normalize eps 1e-12):
  * x fp32 [B][T][F]; W1 [Hd][F], b1 [Hd], W2 [F][Hd], b2 [F], Wp [E][F], bp [E] (Wp may be NULL)
  * saves alpha [B][T][F], hid [B][T][Hd], pooled [B][F], pre [B][E], out [B][E] */

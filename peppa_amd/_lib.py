@@ -82,7 +82,7 @@ SIGNATURES = {
     "pp_dropout_f32": [P, P, L, F, C.c_uint, P],
     "pp_colsum_bf16": [P, L, I, I, P, P],
     "pp_layernorm_fwd": [P, P, P, F, P, P, P, I, I, P],
-    "pp_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, P],
+    "pp_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, P, I, P],
     "pp_softmax_fwd": [P, I, P, I, I, I, F, P],
     "pp_softmax_bwd": [P, I, P, I, P, I, I, F, P],
     "pp_conv0_stats": [P, I, I, I, P, P, P],
@@ -93,6 +93,8 @@ SIGNATURES = {
     "pp_weightnorm_bwd": [P, P, P, P, I, I, I, P, P, P, P],
     "pp_spatial_mean_fwd": [P, P, I, I, I, I, I, P],
     "pp_spatial_mean_bwd": [P, P, I, I, I, I, I, P],
+    "pp_avgpool_tf_fwd": [P, I, I, I, I, P, P],
+    "pp_avgpool_tf_bwd": [P, I, I, I, I, P, P],
     "pp_attnpool_fwd": [P, I, I, I, I, I, P, P, P, P, P, P, I, P, P, P, P, P, P],
     "pp_attnpool_bwd": [P, P, I, I, I, I, I, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "pp_attnpool_ws_floats": [I, I, I, I, I],

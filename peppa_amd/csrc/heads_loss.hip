@@ -126,6 +126,45 @@ __global__ void spatial_mean_bwd_kernel(const float* __restrict__ dout, bfraw* _
   }
 }
 
+// ---- pig/models.py:45-51 AveragePool: nn.AdaptiveAvgPool2d((S, 1)) applied to the 3-D tensor (B, T, F) -------------
+// torch reads a 3-D input as (C, H, W): the pool runs over (T, F) -> (S, 1), i.e. the FEATURE axis is averaged away
+// and the TIME axis is resampled to S bins [floor(i T / S), ceil((i + 1) T / S)).  Kept as the reference computes it.
+__global__ void avgpool_tf_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int F, int S) {
+  extern __shared__ float rowsum[];   // [T]
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int t = wave; t < T; t += nw) {
+    const float* row = x + ((long long)b * T + t) * F;
+    float a = 0.f;
+    for (int f = lane; f < F; f += 64) a += row[f];
+    a = wave_sum(a);
+    if (lane == 0) rowsum[t] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    const int t0 = (int)(((long long)i * T) / S), t1 = (int)((((long long)i + 1) * T + S - 1) / S);
+    float a = 0.f;
+    for (int t = t0; t < t1; ++t) a += rowsum[t];
+    out[(long long)b * S + i] = a / (float)((t1 - t0) * F);
+  }
+}
+__global__ void avgpool_tf_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int T, int F, int S) {
+  extern __shared__ float coef[];     // [T]: d out / d x[b, t, any f]
+  const int b = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    // bins that contain t: i with floor(i T / S) <= t < ceil((i + 1) T / S)  <=>  i in [ceil((t + 1) S / T) - 1 ... floor(t S / T)] reversed;
+    // scanned directly (S is a few hundred)
+    float c = 0.f;
+    const int ilo = (int)(((long long)t * S) / T) - 1, ihi = (int)((((long long)t + 1) * S + T - 1) / T);
+    for (int i = ilo < 0 ? 0 : ilo; i <= ihi && i < S; ++i) {
+      const int t0 = (int)(((long long)i * T) / S), t1 = (int)((((long long)i + 1) * T + S - 1) / S);
+      if (t >= t0 && t < t1) c += dout[(long long)b * S + i] / (float)((t1 - t0) * F);
+    }
+    coef[t] = c;
+  }
+  __syncthreads();
+  for (long long i = threadIdx.x; i < (long long)T * F; i += blockDim.x) dx[(long long)b * T * F + i] = coef[i / F];
+}
+
 // ---- softmax over time per feature + weighted sum ------------------------------------------------
 // e/alpha [B][T][F] in place; pooled[b][f] = sum_t alpha*x
 __global__ void timepool_fwd_kernel(float* __restrict__ ea, const float* __restrict__ x, float* __restrict__ pooled, int T, int F) {
@@ -277,6 +316,19 @@ extern "C" int pp_spatial_mean_bwd(const float* dout, void* dx, int B, int T, in
 
 extern "C" size_t pp_attnpool_ws_floats(int B, int T, int F, int Hd, int E) {
   return (size_t)B * E + (size_t)B * F + (size_t)B * T * F + (size_t)B * T * Hd;
+}
+
+extern "C" int pp_avgpool_tf_fwd(const float* x, int B, int T, int F, int S, float* out, pp_stream_t s) {
+  PP_CHECK_ARG(B > 0 && T > 0 && T <= 8192 && F > 0 && S > 0, "pp_avgpool_tf_fwd: sizes");
+  hipLaunchKernelGGL(avgpool_tf_fwd_kernel, dim3(B), dim3(256), (size_t)T * 4, S_, x, out, T, F, S);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_avgpool_tf_bwd(const float* dout, int B, int T, int F, int S, float* dx, pp_stream_t s) {
+  PP_CHECK_ARG(B > 0 && T > 0 && T <= 8192 && F > 0 && S > 0, "pp_avgpool_tf_bwd: sizes");
+  hipLaunchKernelGGL(avgpool_tf_bwd_kernel, dim3(B), dim3(256), (size_t)T * 4, S_, dout, dx, T, F, S);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
 }
 
 extern "C" int pp_attnpool_fwd(const float* x, int B, int T, int F, int Hd, int E, const float* W1, const float* b1,

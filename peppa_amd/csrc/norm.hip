@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bfraw* __restrict__ x
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bfraw* __restrict__ dy, const bfraw* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, bfraw* __restrict__ dx,
-                                                     float* dgamma, float* dbeta, int rows, int D, int rows_per_wave) {
+                                                     float* dgamma, float* dbeta, int rows, int D, int rows_per_wave,
+                                                     float* __restrict__ ws) {
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nch = D >> 3;
@@ -111,9 +112,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bfraw* __restrict__ d
   }
   __syncthreads();
   for (int i = threadIdx.x; i < D; i += 256) {
-    atomicAdd(dgamma + i, red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
-    atomicAdd(dbeta + i, red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+    const float sg = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
+    const float sb = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
+    if (ws) {   // per-block partials, summed by ln_bwd_partials_kernel: no same-address atomics, deterministic
+      ws[((long long)blockIdx.x * 2 + 0) * D + i] = sg;
+      ws[((long long)blockIdx.x * 2 + 1) * D + i] = sb;
+    } else {
+      atomicAdd(dgamma + i, sg);
+      atomicAdd(dbeta + i, sb);
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_partials_kernel(const float* __restrict__ ws, int nblk, int D,
+                                                              float* dgamma, float* dbeta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // over 2 * D: [0, D) -> dgamma, [D, 2D) -> dbeta
+  if (i >= 2 * D) return;
+  const int which = i >= D, c = i - which * D;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += ws[((long long)b * 2 + which) * D + c];
+  float* out = which ? dbeta : dgamma;
+  out[c] += s;
 }
 
 constexpr int SM_MAXC = 4;  // columns per lane -> T <= 256
@@ -355,14 +374,21 @@ extern "C" int pp_layernorm_fwd(const void* x, const float* gamma, const float* 
   return PP_OK;
 }
 extern "C" int pp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                void* dx, float* dgamma, float* dbeta, int rows, int D, pp_stream_t s) {
+                                void* dx, float* dgamma, float* dbeta, int rows, int D, float* ws, int ws_blocks,
+                                pp_stream_t s) {
   PP_CHECK_ARG(rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC, "pp_layernorm_bwd: D=%d unsupported", D);
-  int waves = (rows + 7) / 8;  // >= 8 rows per wave, at most 512 waves (128 workgroups of atomics)
-  if (waves > 512) waves = 512;
+  // with a workspace ([ws_blocks][2][D] fp32): 4 rows per wave, per-block partials + a second pass; without: few, fat
+  // waves so that the same-address atomics of dgamma / dbeta stay cheap
+  int waves = ws ? (rows + 3) / 4 : (rows + 7) / 8;
+  const int cap = ws ? 4 * ws_blocks : 512;
+  PP_CHECK_ARG(!ws || ws_blocks > 0, "pp_layernorm_bwd: ws_blocks");
+  if (waves > cap) waves = cap;
   const int rows_per_wave = (rows + waves - 1) / waves;
   waves = (rows + rows_per_wave - 1) / rows_per_wave;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, S_, (const bfraw*)dy, (const bfraw*)x, gamma, mean,
-                     rstd, (bfraw*)dx, dgamma, dbeta, rows, D, rows_per_wave);
+  const int nblk = (waves + 3) / 4;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, S_, (const bfraw*)dy, (const bfraw*)x, gamma, mean,
+                     rstd, (bfraw*)dx, dgamma, dbeta, rows, D, rows_per_wave, ws);
+  if (ws) hipLaunchKernelGGL(ln_bwd_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, S_, ws, nblk, D, dgamma, dbeta);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -272,9 +272,10 @@ def layernorm_fwd(x, gamma, beta, eps, y, mean, rstd, rows, D):
          _p(rstd, f32), rows, D, _s())
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, ws=None):
+    """ws: optional fp32 scratch [blocks][2][D] -> two-pass (deterministic) dgamma / dbeta instead of atomics."""
     call("pp_layernorm_bwd", _p(dy, bf16), _p(x, bf16), _p(gamma, f32), _p(mean, f32), _p(rstd, f32), _p(dx, bf16),
-         _p(dgamma, f32), _p(dbeta, f32), rows, D, _s())
+         _p(dgamma, f32), _p(dbeta, f32), rows, D, _p(ws, f32), 0 if ws is None else ws.shape[0], _s())
 
 
 def softmax_fwd(S, lds, P, ldp, nb, T, scale):
@@ -321,6 +322,14 @@ def spatial_mean_fwd(x, out, B, T, HW, Cn, Cp):
 
 def spatial_mean_bwd(dout, dx, B, T, HW, Cn, Cp):
     call("pp_spatial_mean_bwd", _p(dout, f32), _p(dx, bf16), B, T, HW, Cn, Cp, _s())
+
+
+def avgpool_tf_fwd(x, out, B, T, F, S):
+    call("pp_avgpool_tf_fwd", _p(x, f32), B, T, F, S, _p(out, f32), _s())
+
+
+def avgpool_tf_bwd(dout, dx, B, T, F, S):
+    call("pp_avgpool_tf_bwd", _p(dout, f32), B, T, F, S, _p(dx, f32), _s())
 
 
 def attnpool_fwd(x, B, T, Fdim, Hd, E, W1, b1, W2, b2, Wp, bp, hid, alpha, pooled, pre, out, normalize=True):

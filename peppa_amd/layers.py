@@ -310,5 +310,6 @@ def layernorm_bwd(dy, x, ln, saved):
     rows, D = x.shape
     dx = empty(x.shape, bf16, x)
     dg, db = zeros((D,), f32, x), zeros((D,), f32, x)
-    H.layernorm_bwd(dy, x, ln.weight, saved[0], saved[1], dx, dg, db, rows, D)
+    ws = empty((min(512, (rows + 15) // 16), 2, D), f32, x)   # per-workgroup partials (4 waves x 4 rows each)
+    H.layernorm_bwd(dy, x, ln.weight, saved[0], saved[1], dx, dg, db, rows, D, ws)
     return dx, dg, db

@@ -82,18 +82,78 @@ class Attention(nn.Module):
                                 project.weight, project.bias, True)
 
 
-def _hip_todo(what):
-    raise NotImplementedError(f"{what} is not on the HIP path yet (no committed hparams_*.yaml selects it); "
-                              "see DESIGN.md 'Out of scope / next'")
+class _AvgPoolTFFn(torch.autograd.Function):
+    """pig/models.py:45-51: nn.AdaptiveAvgPool2d((size, 1)) on the 3-D (B, T, F) tensor, as torch evaluates it."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        if not x.is_cuda:
+            raise H.PeppaHipError("peppa_amd pooling needs a CUDA/HIP tensor (no CPU fallback)")
+        x = x.contiguous().float()
+        B, T, Fd = x.shape
+        out = torch.empty(B, size, dtype=f32, device=x.device)
+        H.avgpool_tf_fwd(x, out, B, T, Fd, size)
+        ctx.dims = (B, T, Fd, size)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, Fd, size = ctx.dims
+        dx = torch.empty(B, T, Fd, dtype=f32, device=dout.device)
+        H.avgpool_tf_bwd(dout.contiguous().float(), dx, B, T, Fd, size)
+        return dx, None
+
+
+class _LastStepFn(torch.autograd.Function):
+    """x[:, -1, :] (pig/models.py:54-61) as a strided copy; backward scatters into zeros."""
+
+    @staticmethod
+    def forward(ctx, x):
+        if not x.is_cuda:
+            raise H.PeppaHipError("peppa_amd pooling needs a CUDA/HIP tensor (no CPU fallback)")
+        x = x.contiguous().float()
+        B, T, Fd = x.shape
+        out = torch.empty(B, Fd, dtype=f32, device=x.device)
+        H.copy_2d_f32(x.view(B, T * Fd)[:, (T - 1) * Fd:], T * Fd, out, Fd, B, Fd)
+        ctx.dims = (B, T, Fd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, Fd = ctx.dims
+        dx = torch.empty(B, T * Fd, dtype=f32, device=dout.device)
+        H.fill_f32(dx, 0.0)
+        H.copy_2d_f32(dout.contiguous().float(), Fd, dx[:, (T - 1) * Fd:], T * Fd, B, Fd)
+        return dx.view(B, T, Fd)
+
+
+def _project_normalize(pooled, project):
+    """Tail shared by every encoder head: `project` (nn.Linear or nn.Identity), then F.normalize(p=2, dim=1).
+    Runs through the attention-pooling entry with one time step (softmax over a single step is 1, so the pooling
+    is the identity and its dummy attention weights receive zero gradient)."""
+    B, Fd = pooled.shape
+    z = lambda *shape: torch.zeros(*shape, dtype=f32, device=pooled.device)
+    W, b = (project.weight, project.bias) if isinstance(project, nn.Linear) else (None, None)
+    if W is not None and b is None:
+        b = z(W.shape[0])
+    return AttnPoolFn.apply(pooled.view(B, 1, Fd), z(8, Fd), z(8), z(Fd, 8), z(Fd), W, b, True)
+
+
+def _time_mean(x):
+    """Mean over dim 1 of (B, T, F): attention pooling with all-zero scores (softmax of zeros is exactly 1 / T)."""
+    B, T, Fd = x.shape
+    z = lambda *shape: torch.zeros(*shape, dtype=f32, device=x.device)
+    return AttnPoolFn.apply(x, z(8, Fd), z(8), z(Fd, 8), z(Fd), None, None, False)
 
 
 class AveragePool(nn.Module):
     def __init__(self, size=512):
         super().__init__()
-        self.pool = torch.nn.AdaptiveAvgPool2d((size, 1))
+        self.size = size
+        self.pool = torch.nn.AdaptiveAvgPool2d((size, 1))   # (kept for state_dict / repr parity; has no parameters)
 
     def forward(self, x):
-        _hip_todo("audio pooling 'average'")
+        return _AvgPoolTFFn.apply(x, self.size)
 
 
 class LastStep(nn.Module):
@@ -101,7 +161,7 @@ class LastStep(nn.Module):
         super().__init__()
 
     def forward(self, x):
-        _hip_todo("audio pooling 'last'")
+        return _LastStepFn.apply(x)
 
 
 class Wav2VecEncoder(nn.Module):
@@ -138,8 +198,8 @@ class Wav2VecEncoder(nn.Module):
         else:
             features, _ = self.audio.extract_features(wave)
         if isinstance(self.audiopool, Attention) and isinstance(self.project, nn.Linear):
-            return self.audiopool.pooled_projected(features, self.project)
-        _hip_todo("audio head other than attention pooling + projection")
+            return self.audiopool.pooled_projected(features, self.project)    # one fused tail
+        return _project_normalize(self.audiopool(features), self.project)
 
 
 def _load_fairseq_checkpoint(path):
@@ -231,7 +291,7 @@ class R3DEncoder(nn.Module):
         feats = VideoTrunkFn.apply(x, self, torch.is_grad_enabled(), *self.video.trunk_parameters())
         if isinstance(self.videopool, VideoAttention) and isinstance(self.project, nn.Linear):
             return self.videopool.attn.pooled_projected(feats, self.project)
-        _hip_todo("video head other than attention pooling + projection")
+        return _project_normalize(self.videopool(feats), self.project)
 
 
 class ImageEncoder(nn.Module):
@@ -252,7 +312,7 @@ class ImageEncoder(nn.Module):
         if pooling == 'attention':
             self.pool = Attention(512, 128)
         elif pooling == 'average':
-            self.pool = lambda x: _hip_todo("static video pooling 'average'")
+            self.pool = _time_mean                    # x.mean(dim=1) over the frames (pig/models.py:173)
         else:
             raise ValueError(f"Invalid pooling {pooling}")
 
@@ -264,7 +324,7 @@ class ImageEncoder(nn.Module):
         feats = VideoTrunkFn.apply(x, self, torch.is_grad_enabled(), *self.image.trunk_parameters())
         if isinstance(self.pool, Attention) and isinstance(self.project, nn.Linear):
             return self.pool.pooled_projected(feats, self.project)
-        _hip_todo("static video head other than attention pooling + projection")
+        return _project_normalize(self.pool(feats), self.project)
 
 
 class VideoAveragePool(nn.Module):
@@ -273,7 +333,8 @@ class VideoAveragePool(nn.Module):
         self.pool = torch.nn.AdaptiveAvgPool3d(output_size=(1, 1, 1))
 
     def forward(self, x):
-        _hip_todo("video pooling 'average'")
+        """x: spatial means (B,T',512) as produced by VideoTrunkFn; AdaptiveAvgPool3d((1,1,1)) = their mean over T'."""
+        return _time_mean(x)
 
 
 class VideoAttention(nn.Module):

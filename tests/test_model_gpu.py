@@ -348,3 +348,43 @@ def test_audio_dropout_and_layerdrop_train_mode():
     assert (E1 - E2).abs().max().item() < 2e-3
     # dropout is unbiased: the train-mode embedding stays close to the eval-mode one
     assert F.cosine_similarity(A1.detach(), E1, dim=1).min().item() > 0.5
+
+
+@pytest.mark.parametrize("pooling,project,T,Fd", [("average", True, 49, 28), ("average", False, 114, 512), ("last", True, 7, 28),
+                                                  ("last", False, 5, 512), ("vavg", True, 3, 512), ("vavg", False, 2, 512)])
+def test_remaining_pooling_heads_match_reference_semantics(pooling, project, T, Fd):
+    """`average` / `last` audio pooling, VideoAveragePool, and `project: false` (pig/models.py:45-61, 97-109, 204-211):
+    the HIP heads against the reference expressions evaluated by torch on the CPU, values and gradients.
+    (AveragePool is nn.AdaptiveAvgPool2d((size, 1)) on a 3-D tensor: it averages the FEATURE axis and resamples time.)"""
+    from peppa_amd import models as PM
+    g = torch.Generator().manual_seed(T * 31 + Fd)
+    B = 5
+    x = torch.randn(B, T, Fd, generator=g)
+    lin = torch.nn.Linear(Fd, 512) if project else torch.nn.Identity()
+    R = torch.randn(B, 512 if project else Fd, generator=g)
+    # reference expressions
+    xr = x.clone().requires_grad_()
+    if pooling == "average":
+        pooled = torch.nn.AdaptiveAvgPool2d((Fd, 1))(xr).squeeze(dim=2)
+    elif pooling == "last":
+        pooled = xr[:, -1, :]
+    else:   # VideoAveragePool on (B, 512, T, H, W) == mean over T of the spatial means
+        pooled = xr.mean(dim=1)
+    out_ref = F.normalize(lin(pooled), p=2, dim=1)
+    (out_ref * R).sum().backward()
+    # HIP heads
+    xd = x.clone().to(DEV).requires_grad_()
+    lind = copy.deepcopy(lin).to(DEV)
+    if pooling == "average":
+        head = PM.AveragePool(size=Fd)
+    elif pooling == "last":
+        head = PM.LastStep()
+    else:
+        head = PM.VideoAveragePool()
+    out = PM._project_normalize(head(xd), lind)
+    (out * R.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    assert (out.detach().cpu() - out_ref.detach()).abs().max().item() <= 2e-5
+    assert rel(xd.grad, xr.grad) <= 2e-4
+    if project:
+        assert rel(lind.weight.grad, lin.weight.grad) <= 2e-4 and rel(lind.bias.grad, lin.bias.grad) <= 2e-4
