@@ -241,6 +241,13 @@ int pp_contrastive_fwd(const float* S, int N, float margin, float* loss, float* 
 /* pig/metrics.py:45-52 triplet_accuracy: a, p, n fp32 [M][D] -> out [M] ((sign(diff)+1)/2 or diff) */
 int pp_triplet_accuracy(const float* a, const float* p, const float* n, int M, int D, int discrete, float* out,
                         pp_stream_t s);
+/* Rank-based recall of pig/metrics.py:7-42 (recall_at_n, recall_at_1_to_n) and :54-81 (resampled_*), batched on device.
+ * S [Nr][ld] fp32 similarities (rows = references / queries, columns = candidates); positions follow the ascending order
+ * of 1 - S, ties by index.  idx = NULL: one problem over the whole matrix; else nsets index sets [nsets][size] (int32),
+ * set t ranks row idx[t][j] against columns idx[t][*].  correct = NULL: the target of row j is column j (torch.eye);
+ * else [Nr][Nc] bytes, non-zero = target.  out [nsets][Nmax][rows] = recall@1..Nmax per row. */
+int pp_recall_at_n(const float* S, int Nr, int Nc, int ld, const int* idx, int nsets, int size,
+                   const unsigned char* correct, int Nmax, float* out, pp_stream_t s);
 
 /* ---- pig/optimization.py:101-179 BertAdam.step (multi-tensor) --------------------------- */
 typedef struct pp_tensor_list {

@@ -101,6 +101,7 @@ SIGNATURES = {
     "pp_triplet_workspace_bytes": [I, I],
     "pp_triplet_loss_fwd": [P, P, I, I, F, P, P, Z, P],
     "pp_triplet_loss_bwd": [P, P, I, I, P, P, P, P, P],
+    "pp_recall_at_n": [P, I, I, I, P, I, I, P, I, P, P],
     "pp_cosine_matrix": [P, P, I, I, I, P, P, P],
     "pp_contrastive_fwd": [P, I, F, P, P, P],
     "pp_triplet_accuracy": [P, P, P, I, I, I, P, P],

@@ -430,12 +430,61 @@ __global__ __launch_bounds__(256) void triplet_acc_kernel(const float* __restric
     out[r] = discrete ? ((diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) + 1.f) * 0.5f : diff;
   }
 }
+// ---- rank-based recall (pig/metrics.py:7-42, 54-81) on a similarity matrix ----------------------------------------
+// One workgroup per (query row, index set).  The reference sorts distances 1 - cos ascending and intersects the first n
+// positions with the targets; element k sits at position #{k' : d[k'] < d[k], or d[k'] == d[k] and k' < k}, so no sort
+// is needed: every target counts the candidates ahead of it.  hist[r] = targets at position r; recall@n = prefix / #targets.
+__global__ __launch_bounds__(256) void recall_kernel(const float* __restrict__ S, int Nc, int ld, const int* __restrict__ idx,
+                                                     int size, const unsigned char* __restrict__ correct, int Nmax,
+                                                     float* __restrict__ out) {
+  extern __shared__ float dist[];            // [ncols] distances of this row, then Nmax + 1 ints
+  const int j = blockIdx.x, set = blockIdx.y;
+  const int ncols = idx ? size : Nc;
+  int* hist = (int*)(dist + ncols);          // hist[0 .. Nmax-1], hist[Nmax] = number of targets
+  const int* ix = idx ? idx + (long long)set * size : nullptr;
+  const int row = ix ? ix[j] : j;
+  for (int k = threadIdx.x; k < ncols; k += 256) dist[k] = 1.f - S[(long long)row * ld + (ix ? ix[k] : k)];
+  for (int n = threadIdx.x; n <= Nmax; n += 256) hist[n] = 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < ncols; k += 256) {
+    const bool target = correct ? correct[(long long)row * Nc + (ix ? ix[k] : k)] != 0 : k == j;
+    if (!target) continue;
+    const float dk = dist[k];
+    int pos = 0;
+    for (int q = 0; q < ncols; ++q) pos += (dist[q] < dk) || (dist[q] == dk && q < k);
+    atomicAdd(&hist[Nmax], 1);
+    if (pos < Nmax) atomicAdd(&hist[pos], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float nt = (float)hist[Nmax];      // (no targets: 0 / 0 = NaN; the reference raises ZeroDivisionError)
+    int acc = 0;
+    for (int n = 1; n <= Nmax; ++n) {
+      acc += hist[n - 1];
+      out[((long long)set * Nmax + (n - 1)) * gridDim.x + j] = (float)acc / nt;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pp_triplet_accuracy(const float* a, const float* p, const float* n, int M, int D, int discrete, float* out,
                                    pp_stream_t s) {
   PP_CHECK_ARG(M > 0 && D > 0 && a && p && n && out, "pp_triplet_accuracy: bad arguments");
   hipLaunchKernelGGL(triplet_acc_kernel, dim3(M), dim3(256), 0, S_, a, p, n, D, discrete, out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_recall_at_n(const float* S, int Nr, int Nc, int ld, const int* idx, int nsets, int size,
+                              const unsigned char* correct, int Nmax, float* out, pp_stream_t s) {
+  PP_CHECK_ARG(S && out && Nr > 0 && Nc > 0 && ld >= Nc && Nmax > 0 && Nmax <= 4096, "pp_recall_at_n: bad arguments");
+  PP_CHECK_ARG(idx ? (nsets > 0 && size > 0) : true, "pp_recall_at_n: index sets");
+  const int rows = idx ? size : Nr, ncols = idx ? size : Nc, sets = idx ? nsets : 1;
+  PP_CHECK_ARG(correct || ncols >= rows, "pp_recall_at_n: identity targets need a column per row");
+  const size_t shm = (size_t)ncols * 4 + (size_t)(Nmax + 1) * 4;
+  PP_CHECK_ARG(shm <= 64 * 1024, "pp_recall_at_n: %d candidates per row exceed the LDS staging (max ~16000)", ncols);
+  hipLaunchKernelGGL(recall_kernel, dim3(rows, sets), dim3(256), shm, S_, S, Nc, ld, idx, size, correct, Nmax, out);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

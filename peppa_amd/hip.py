@@ -365,6 +365,14 @@ def triplet_loss_bwd(V, A, dloss, ws, dV, dA):
     call("pp_triplet_loss_bwd", _p(V, f32), _p(A, f32), N, D, _p(dloss, f32), _p(ws), _p(dV, f32), _p(dA, f32), _s())
 
 
+def recall_at_n(S, idx, correct, Nmax, out):
+    """S fp32 (Nr, Nc); idx int32 (nsets, size) or None; correct uint8 (Nr, Nc) or None; out fp32 (nsets, Nmax, rows)."""
+    Nr, Nc = S.shape
+    nsets, size = (idx.shape if idx is not None else (1, Nr))
+    call("pp_recall_at_n", _p(S, f32), Nr, Nc, S.stride(0), _p(idx, torch.int32), nsets, size, _p(correct, torch.uint8), Nmax,
+         _p(out, f32), _s())
+
+
 def cosine_matrix(U, V, out):
     ws = torch.empty((U.shape[0] + V.shape[0]) * U.shape[1], dtype=f32, device=U.device)
     call("pp_cosine_matrix", _p(U, f32), _p(V, f32), U.shape[0], V.shape[0], U.shape[1], _p(out, f32), _p(ws, f32), _s())

@@ -1,6 +1,5 @@
-"""`pig.metrics` (pig/metrics.py:7-81).  triplet_accuracy and the similarity matrix run on the HIP
-path; the rank-based recall loops stay host-side like the reference's (validation only; a batched
-device version is listed under "next" in DESIGN.md)."""
+"""`pig.metrics` (pig/metrics.py:7-81) on the HIP path: triplet_accuracy, the similarity matrix and the rank-based
+recalls (one launch for all index sets of resampled_recall instead of n_samples x size host-side argsorts)."""
 import torch
 
 from . import hip as H
@@ -22,58 +21,54 @@ def batch_triplet_accuracy(batch):
     return triplet_accuracy(batch.anchor, batch.positive, batch.negative)
 
 
-def _ranked(candidates, references):
-    distances = 1 - cosine_matrix(references, candidates)
-    return distances.cpu()
+def _recall_table(candidates, references, correct, Nmax, idx=None):
+    """recall@1..Nmax per query row, evaluated on the device: (nsets, Nmax, rows) fp32 on the CPU.
+
+    Positions are those of the reference's `row.argsort()` over 1 - cosine (ties by index); instead of sorting,
+    every target counts the candidates ahead of it (pp_recall_at_n)."""
+    S = cosine_matrix(references, candidates)                       # (len(references), len(candidates)) on the device
+    if correct is not None:
+        correct = (correct != 0).to(device=S.device, dtype=torch.uint8).contiguous()
+        if correct.shape != S.shape:
+            raise ValueError(f"correct has shape {tuple(correct.shape)}, expected {tuple(S.shape)}")
+    if idx is not None:
+        idx = idx.to(device=S.device, dtype=torch.int32).contiguous()
+    nsets, rows = (idx.shape if idx is not None else (1, S.shape[0]))
+    out = torch.empty(nsets, Nmax, rows, dtype=f32, device=S.device)
+    H.recall_at_n(S, idx, correct, Nmax, out)
+    return out.cpu()
 
 
 def recall_at_n(candidates, references, correct, n=1):
-    distances = _ranked(candidates, references)
-    correct = correct.cpu()
-    recall = []
-    for j, row in enumerate(distances):
-        topn = row.argsort()[:n]
-        target = torch.nonzero(correct[j])[:, 0]
-        overlap = (topn.unsqueeze(dim=0) == target.unsqueeze(dim=1)).sum().item()
-        recall.append(overlap / len(target))
-    return torch.tensor(recall)
+    return _recall_table(candidates, references, correct, n)[0, n - 1]
 
 
 def recall_at_1_to_n(candidates, references, correct, N=1):
-    distances = _ranked(candidates, references)
-    correct = correct.cpu()
-    recall = [[] for _ in range(0, N + 1)]
-    recall[0] = [0 for _ in distances]
-    for j, row in enumerate(distances):
-        ranked = row.argsort()
-        target = torch.nonzero(correct[j])[:, 0]
-        for n in range(1, N + 1):
-            overlap = (ranked[:n].unsqueeze(dim=0) == target.unsqueeze(dim=1)).sum().item()
-            recall[n].append(overlap / len(target))
-    return torch.tensor(recall)
+    table = _recall_table(candidates, references, correct, N)[0]   # (N, rows)
+    return torch.cat([torch.zeros(1, table.shape[1]), table], dim=0)   # recall at 0 is always zero
 
 
 def sample_indices(x, size):
     return torch.randperm(x.size(0))[:size]
 
 
+def _index_sets(x, size, n_samples):
+    # one torch.randperm per sample from the global CPU generator, exactly the draws the reference makes
+    return torch.stack([sample_indices(x, size) for _ in range(n_samples)])
+
+
 def resampled_recall(candidates, references, size=100, n_samples=100, n=1):
+    """(n_samples, size): all index sets are ranked by ONE launch on one similarity matrix (the reference does
+    n_samples x size host-side argsorts); targets are the diagonal (torch.eye in the reference)."""
     assert len(candidates) == len(references)
     assert len(candidates) >= size
-    result = []
-    for _ in range(n_samples):
-        ix = sample_indices(candidates, size).to(candidates.device)
-        X, Y = candidates[ix], references[ix]
-        result.append(recall_at_n(X, Y, torch.eye(X.shape[0]), n=n))
-    return torch.stack(result)
+    ix = _index_sets(candidates, size, n_samples)
+    return _recall_table(candidates, references, None, n, idx=ix)[:, n - 1, :]
 
 
 def resampled_recall_at_1_to_n(candidates, references, size=100, n_samples=100, N=1):
     assert len(candidates) == len(references)
     assert len(candidates) >= size
-    result = []
-    for _ in range(n_samples):
-        ix = sample_indices(candidates, size).to(candidates.device)
-        X, Y = candidates[ix], references[ix]
-        result.append(recall_at_1_to_n(X, Y, torch.eye(X.shape[0]), N=N))
-    return torch.stack(result)
+    ix = _index_sets(candidates, size, n_samples)
+    table = _recall_table(candidates, references, None, N, idx=ix)   # (n_samples, N, size)
+    return torch.cat([torch.zeros(n_samples, 1, size), table], dim=1)

@@ -773,3 +773,51 @@ def test_temporal_window_wgrad_matches_generic(case):
     dw = torch.empty(Co, Ci, *k, dtype=torch.float32, device=DEV)
     H.unprep_conv_grad(outs[1], dw, geom.Co, geom.Cig, geom.taps, geom.cg_in)
     close(dw, w.grad, name="temporal window wgrad vs torch")
+
+
+def _ref_recall_at_1_to_n(candidates, references, correct, N):
+    """The reference's algorithm (pig/metrics.py:23-42) restated with plain torch on the CPU."""
+    cn = candidates / candidates.norm(dim=1, keepdim=True)
+    rn = references / references.norm(dim=1, keepdim=True)
+    distances = 1 - rn @ cn.t()
+    recall = [[0.0 for _ in distances]] + [[] for _ in range(N)]
+    for j, row in enumerate(distances):
+        ranked = row.argsort(stable=True)
+        target = torch.nonzero(correct[j])[:, 0]
+        for n in range(1, N + 1):
+            overlap = (ranked[:n].unsqueeze(0) == target.unsqueeze(1)).sum().item()
+            recall[n].append(overlap / len(target))
+    return torch.tensor(recall)
+
+
+def test_recall_metrics_on_device(golden_dir):
+    """pig.metrics recall_at_n / recall_at_1_to_n / resampled_recall on the HIP path: the reference's golden vectors
+    (generated by the live reference, oracle/make_golden.py), multi-target rows, and the batched resampled variant."""
+    import pig.metrics as M
+    z = np.load(os.path.join(golden_dir, "ref_metrics.npz"))
+    cand, ref = torch.from_numpy(z["cand"]).to(DEV), torch.from_numpy(z["ref"]).to(DEV)
+    r3 = M.recall_at_n(cand, ref, torch.eye(16), n=3)
+    r14 = M.recall_at_1_to_n(cand, ref, torch.eye(16), N=4)
+    assert torch.equal(r3, torch.from_numpy(z["recall_at_3"]).float())
+    assert torch.equal(r14, torch.from_numpy(z["recall_1_to_4"]).float())
+    # several targets per row, rectangular problem
+    g = torch.Generator().manual_seed(9)
+    C, R = torch.randn(37, 64, generator=g), torch.randn(23, 64, generator=g)
+    correct = (torch.rand(23, 37, generator=g) < 0.15)
+    correct[:, 0] = True   # every row has at least one target
+    got = M.recall_at_1_to_n(C.to(DEV), R.to(DEV), correct.float(), N=6)
+    assert torch.allclose(got, _ref_recall_at_1_to_n(C, R, correct, 6), atol=1e-6)
+    # resampled: same index draws as the reference (global CPU generator), one launch for all sets
+    X, Y = torch.randn(150, 32, generator=g), torch.randn(150, 32, generator=g)
+    Y = Y + 0.5 * X   # make the diagonal retrievable
+    torch.manual_seed(123)
+    got = M.resampled_recall(X.to(DEV), Y.to(DEV), size=100, n_samples=7, n=5)
+    torch.manual_seed(123)
+    want = []
+    for _ in range(7):
+        ix = torch.randperm(150)[:100]
+        want.append(_ref_recall_at_1_to_n(X[ix], Y[ix], torch.eye(100), 5)[5])
+    assert got.shape == (7, 100) and torch.allclose(got, torch.stack(want), atol=1e-6)
+    torch.manual_seed(5)
+    t = M.resampled_recall_at_1_to_n(X.to(DEV), Y.to(DEV), size=100, n_samples=3, N=4)
+    assert t.shape == (3, 5, 100) and (t[:, 0] == 0).all() and (t[:, 1:].diff(dim=1) >= 0).all()
