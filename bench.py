@@ -33,38 +33,49 @@ HBM_PEAK = 8.0e12
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=112)
     ap.add_argument("--samples", type=int, default=36800)
     ap.add_argument("--config", default=os.path.join(ROOT, "hparams_base.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8)
     return ap.parse_args()
 
 
 def cpu_baseline(cfg, args):
     """The CPU oracle (fp32, torch CPU threads) on a bounded sample of the same workload."""
     from oracle import model as O
-    try:  # threads actually available to this process (cgroup / affinity), not the host's core count
-        torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    # threads actually available to this process: the affinity mask can list every core of the host while the cgroup
+    # grants a one-GPU box 16 of them -- more threads than that only oversubscribes (minutes instead of seconds)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
     except Exception:
-        pass
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu)))
+    print(f"[bench] cpu_baseline: one oracle step at batch {args.cpu_batch} on {torch.get_num_threads()} threads ...",
+          file=sys.stderr, flush=True)
     torch.manual_seed(0)
     net = O.PeppaPigOracle(cfg, dropout=0.0, layer_drop=0.0).train()
     v, a = O.synthetic_batch(args.cpu_batch, args.frames, args.size, args.samples)
     params = [p for p in net.parameters()]
     state = {}
-    t0 = time.perf_counter()
-    loss = net.training_loss(v, a)
-    loss.backward()
-    with torch.no_grad():
-        O.bertadam_step(params, [p.grad for p in params], state, **{k: cfg["optimizer"][k] for k in ("lr", "warmup", "t_total")})
-    dt = time.perf_counter() - t0
-    return {"value": args.cpu_batch / dt, "unit": "clip-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 full training step (fwd+loss+bwd+BertAdam) of the fp32 CPU oracle at batch {args.cpu_batch}, "
+    nsteps, t0 = 0, time.perf_counter()
+    while True:   # whole training steps until ~10 s of CPU work have been sampled (at most 6 steps)
+        for p in params:
+            p.grad = None
+        loss = net.training_loss(v, a)
+        loss.backward()
+        with torch.no_grad():
+            O.bertadam_step(params, [p.grad for p in params], state, **{k: cfg["optimizer"][k] for k in ("lr", "warmup", "t_total")})
+        nsteps += 1
+        dt = time.perf_counter() - t0
+        if dt >= 10.0 or nsteps >= 6:
+            break
+    return {"value": args.cpu_batch * nsteps / dt, "unit": "clip-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nsteps} full training steps (fwd+loss+bwd+BertAdam) of the fp32 CPU oracle at batch {args.cpu_batch}, "
                       f"{args.frames}x{args.size}x{args.size} video + {args.samples} audio samples, {dt:.1f} s"}
 
 
