@@ -101,6 +101,9 @@ int pp_unprep_conv_grad(const float* g, int Co, int Ci, int taps, int cg, float*
  * r < rows_out, c < cols_out; zero outside rows x cols */
 int pp_cast_pad_2d(const float* in, int rows, int cols, int ld_in, void* out, int rows_out, int cols_out,
                    int ld_out, int transpose, pp_stream_t s);
+/* the same for a DEVICE table of n jobs in one launch.  Job = 10 x int64: {in (const float*), out, rows, cols, ld_in,
+ * rows_out, cols_out, ld_out, transpose, out_f32 (1: fp32 output, a strided copy; 0: bf16)} */
+int pp_cast_pad_2d_multi(const void* items, int n, int blocks_per_item, pp_stream_t s);
 int pp_cast_f32_to_bf16(const float* in, void* out, long long n, pp_stream_t s);
 int pp_cast_bf16_to_f32(const void* in, float* out, long long n, pp_stream_t s);
 /* strided fp32 2-D copy: out[r*ld_out + c] = in[r*ld_in + c] */

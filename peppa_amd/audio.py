@@ -230,19 +230,32 @@ def _fe_backward(fe, t, dfeat, grads):
         grads[gn.weight], grads[gn.bias] = dg, db
 
 
-def _prep_qkv(att, need_dgrad):
-    """q/k/v projections fused into one [2304][768] operand (+ its transpose) and one bias vector."""
+def _prep_qkv(att, need_dgrad, batch):
+    """q/k/v projections fused into one [2304][768] operand (+ its transpose) and one bias vector (jobs of `batch`)."""
     lins = (att.q_proj, att.k_proj, att.v_proj)
     w0 = lins[0].weight
     wf = L.empty((2304, 768), bf16, w0)
     wt = L.empty((768, 2304), bf16, w0) if need_dgrad else None
     bias = L.empty((2304,), f32, w0)
     for i, lin in enumerate(lins):
-        H.cast_pad_2d(lin.weight, wf[i * 768:], 768, 768, 768, 768, 768)
+        batch.cast(lin.weight, wf[i * 768:], 768, 768, 768, 768, 768, 768)
         if need_dgrad:
-            H.cast_pad_2d(lin.weight, wt[:, i * 768:], 768, 768, 768, 768, 2304, transpose=True, cols_out=768)
-        H.copy_2d_f32(lin.bias, 768, bias[i * 768:], 768, 1, 768)
+            batch.cast(lin.weight, wt[:, i * 768:], 768, 768, 768, 768, 768, 2304, transpose=True)
+        batch.cast(lin.bias, bias[i * 768:], 1, 768, 768, 1, 768, 768, out_f32=True)
     return wf, wt, bias
+
+
+def _prep_encoder_weights(enc, save):
+    """Every Linear operand of the encoder (bf16 [N][K] and, for the backward pass, its transpose) in ONE launch."""
+    fp, tr = enc.feature_projection, enc.transformer
+    batch = L.CastBatch()
+    w = {"proj": batch.linear(fp.projection.weight, save), "readout": batch.linear(enc.readout.weight, save)}
+    for layer in tr.layers:
+        att, ff = layer.attention, layer.feed_forward
+        w[layer] = (_prep_qkv(att, save, batch), batch.linear(att.out_proj.weight, save),
+                    batch.linear(ff.intermediate_dense.weight, save), batch.linear(ff.output_dense.weight, save))
+    batch.run(fp.projection.weight.device)
+    return w, batch
 
 
 def _attention_fwd(qkv, B, T, Tp, scale, save, drop=(0.0, 0)):
@@ -318,7 +331,8 @@ def _enc_forward(enc, feat, B, T, save, training=False):
     t.feat = feat
     xln, t.ln0 = L.layernorm_fwd(feat, fp.layer_norm, fp.layer_norm.eps)
     t.xln = xln
-    wf, t.proj_wt = L.prep_linear(fp.projection.weight, need_dgrad=save)
+    W, t.prep_batch = _prep_encoder_weights(enc, save)
+    wf, t.proj_wt = W["proj"]
     x0 = L.linear_fwd(xln, M, wf, 768, bias=fp.projection.bias)
     drop = _Drop(training)
     t.d_fp = drop.site(fp.dropout)
@@ -351,12 +365,12 @@ def _enc_forward(enc, feat, B, T, save, training=False):
         att, ff = layer.attention, layer.feed_forward
         r.d_att, r.d_out = drop.site(att.dropout), drop.site(layer.dropout)
         r.d_int, r.d_ffo = drop.site(ff.intermediate_dropout), drop.site(ff.output_dropout)
-        wf, r.qkv_wt, bqkv = _prep_qkv(att, save)
+        (wf, r.qkv_wt, bqkv), w_out, w_ff1, w_ff2 = W[layer]
         r.x_in = x
         qkv = L.linear_fwd(x, M, wf, 2304, bias=bqkv)
         ctx, r.P = _attention_fwd(qkv, B, T, Tp, att.scaling, save, r.d_att)
         r.qkv, r.ctx = qkv, ctx
-        wf, r.out_wt = L.prep_linear(att.out_proj.weight, need_dgrad=save)
+        wf, r.out_wt = w_out
         if r.d_out[0] > 0:
             t1 = L.linear_fwd(ctx, M, wf, 768, bias=att.out_proj.bias)
             s1 = L.empty(t1.shape, bf16, t1)
@@ -365,13 +379,13 @@ def _enc_forward(enc, feat, B, T, save, training=False):
             s1 = L.linear_fwd(ctx, M, wf, 768, bias=att.out_proj.bias, residual=x)
         xa, r.lnA = L.layernorm_fwd(s1, layer.layer_norm, layer.layer_norm.eps)
         r.s1, r.xa = s1, xa
-        wf, r.ff1_wt = L.prep_linear(ff.intermediate_dense.weight, need_dgrad=save)
+        wf, r.ff1_wt = w_ff1
         r.u = L.empty((M, 3072), bf16, feat) if save else None
         h = L.linear_fwd(xa, M, wf, 3072, bias=ff.intermediate_dense.bias, act=H.ACT_GELU, pre=r.u)
         if r.d_int[0] > 0:
             H.dropout_bf16(h, h, *r.d_int)
         r.h = h
-        wf, r.ff2_wt = L.prep_linear(ff.output_dense.weight, need_dgrad=save)
+        wf, r.ff2_wt = w_ff2
         if r.d_ffo[0] > 0:
             t2 = L.linear_fwd(h, M, wf, 768, bias=ff.output_dense.bias)
             s2 = L.empty(t2.shape, bf16, t2)
@@ -383,7 +397,7 @@ def _enc_forward(enc, feat, B, T, save, training=False):
         t.layers.append(r)
     t.x_final = x
     n_out = enc.readout.out_features
-    wf, t.ro_wt = L.prep_linear(enc.readout.weight, need_dgrad=save)
+    wf, t.ro_wt = W["readout"]
     out = L.empty((M, n_out), f32, feat)
     H.igemm(x, wf, out, M, n_out, 768, H.gather_dense(768), 768, n_out, b_rows=n_out, bias=enc.readout.bias)
     return out, t

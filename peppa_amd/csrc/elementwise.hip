@@ -79,6 +79,21 @@ __global__ void cast_pad_2d_kernel(const float* __restrict__ in, int rows, int c
   }
 }
 
+// the same, for a device table of jobs in one launch (blockIdx.y = job): the ~140 per-step weight casts of the audio
+// tower are 3-8 us launches each; as one launch they are a few
+struct CastItem { const float* in; void* out; long long rows, cols, ld_in, rows_out, cols_out, ld_out, transpose, out_f32; };
+__global__ void cast_pad_2d_multi_kernel(const CastItem* __restrict__ items) {
+  const CastItem it = items[blockIdx.y];
+  const long long n = it.rows_out * it.cols_out;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / it.cols_out, c = i - r * it.cols_out;
+    float v = 0.f;
+    if (r < it.rows && c < it.cols) v = it.transpose ? it.in[c * it.ld_in + r] : it.in[r * it.ld_in + c];
+    if (it.out_f32) ((float*)it.out)[r * it.ld_out + c] = v;
+    else ((bfraw*)it.out)[r * it.ld_out + c] = f2bf(v);
+  }
+}
+
 // w [Co][Ci][taps] -> out[row][tap][cg]; row = co (or ci when transpose_io), channel = ci (or co)
 __global__ void prep_conv_kernel(const float* __restrict__ w, int Co, int Ci, int taps, bfraw* __restrict__ out,
                                  int rows_out, int cg, int transpose_io, int flip, float scale) {
@@ -220,6 +235,13 @@ extern "C" int pp_cast_pad_2d(const float* in, int rows, int cols, int ld_in, vo
   PP_CHECK_ARG(rows > 0 && cols > 0 && rows_out >= rows && cols_out >= cols && ld_out >= cols_out, "pp_cast_pad_2d: sizes");
   hipLaunchKernelGGL(cast_pad_2d_kernel, dim3(sgrid((long long)rows_out * cols_out)), dim3(256), 0, S_, in, rows, cols, ld_in,
                      (bfraw*)out, rows_out, cols_out, ld_out, transpose);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_cast_pad_2d_multi(const void* items, int n, int blocks_per_item, pp_stream_t s) {
+  PP_CHECK_ARG(items && n > 0 && n <= 65535 && blocks_per_item > 0, "pp_cast_pad_2d_multi: bad arguments");
+  static_assert(sizeof(CastItem) == 80, "pp_cast2d_item layout (10 x 8 bytes)");
+  hipLaunchKernelGGL(cast_pad_2d_multi_kernel, dim3(blocks_per_item, n), dim3(256), 0, S_, (const CastItem*)items);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

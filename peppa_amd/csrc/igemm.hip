@@ -20,7 +20,7 @@ int pp_opt_persistent = 1;
 int pp_opt_win_igemm = 1024;   // window kernel for (1,3,3) stride-1 convs (forward / data gradient) once M >= this (0 = never)
 int pp_opt_sw_wgrad = 4096;    // sliding-window weight gradient for (1,3,3) stride-1 convs once M >= this (0 = never)
 int pp_opt_ring_wgrad = 0;      // LDS-DMA ring weight gradient once the reduce dimension has this many rows (0 = never)
-int pp_opt_ring = 192; // LDS-DMA ring variant once there are this many 256-row tiles (0 = never)
+int pp_opt_ring = 128; // LDS-DMA ring variant once there are this many 256-row tiles (0 = never)
 int pp_opt_xcd_remap_wgrad = 1;
 extern "C" int pp_set_option(const char* name, int value) {
   if (!name) return PP_ERR_INVALID;

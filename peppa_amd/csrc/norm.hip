@@ -126,13 +126,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bfraw* __restrict__ d
 
 __global__ __launch_bounds__(256) void ln_bwd_partials_kernel(const float* __restrict__ ws, int nblk, int D,
                                                               float* dgamma, float* dbeta) {
-  const int i = blockIdx.x * 256 + threadIdx.x;   // over 2 * D: [0, D) -> dgamma, [D, 2D) -> dbeta
-  if (i >= 2 * D) return;
-  const int which = i >= D, c = i - which * D;
+  // 16 columns x 16 slices of the partial rows per workgroup (columns run over 2 * D: dgamma then dbeta)
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += ws[((long long)b * 2 + which) * D + c];
-  float* out = which ? dbeta : dgamma;
-  out[c] += s;
+  if (i < 2 * D) {
+    const int which = i >= D, c = i - which * D;
+    for (int b = part; b < nblk; b += 16) s += ws[((long long)b * 2 + which) * D + c];
+  }
+  red[part][cl] = s;
+  __syncthreads();
+  if (part == 0 && i < 2 * D) {
+    for (int q = 1; q < 16; ++q) s += red[q][cl];
+    const int which = i >= D, c = i - which * D;
+    (which ? dbeta : dgamma)[c] += s;
+  }
 }
 
 constexpr int SM_MAXC = 4;  // columns per lane -> T <= 256
@@ -388,7 +397,7 @@ extern "C" int pp_layernorm_bwd(const void* dy, const void* x, const float* gamm
   const int nblk = (waves + 3) / 4;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, S_, (const bfraw*)dy, (const bfraw*)x, gamma, mean,
                      rstd, (bfraw*)dx, dgamma, dbeta, rows, D, rows_per_wave, ws);
-  if (ws) hipLaunchKernelGGL(ln_bwd_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, S_, ws, nblk, D, dgamma, dbeta);
+  if (ws) hipLaunchKernelGGL(ln_bwd_partials_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, S_, ws, nblk, D, dgamma, dbeta);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -58,7 +58,7 @@ def gather_conv(mode, R, G, k, s, p, cg, cstride):
 RING_WGRAD_DEFAULT = 0     # pp_set_option("ring_wgrad", n): LDS-DMA ring weight gradient once M >= n rows (0 = never)
 SW_WGRAD_DEFAULT = 4096   # pp_set_option("sw_wgrad", n): sliding-window wgrad of (1,3,3) stride-1 convs once M >= n (0 = never)
 WIN_IGEMM_DEFAULT = 1024   # pp_set_option("win_igemm", n): window conv kernel for (1,3,3) stride-1 convs once M >= n (0 = never)
-RING_IGEMM_DEFAULT = 192   # pp_set_option("ring_igemm", n): LDS-DMA ring GEMM once there are n 256-row tiles (0 = never)
+RING_IGEMM_DEFAULT = 128   # pp_set_option("ring_igemm", n): LDS-DMA ring GEMM once there are n 256-row tiles (0 = never)
 
 
 # ---- optional in-process kernel timing (bench.py roofline): HIP events on the launch stream ----------
@@ -175,6 +175,18 @@ def cast_f32_to_bf16(inp, out):
 
 def cast_bf16_to_f32(inp, out):
     call("pp_cast_bf16_to_f32", _p(inp, bf16), _p(out, f32), inp.numel(), _s())
+
+
+def cast_pad_2d_multi(jobs, device):
+    """jobs: [(in fp32, out, rows, cols, ld_in, rows_out, cols_out, ld_out, transpose, out_f32)] -> one launch.
+    Returns the device table (keep it alive until the launch has run: stream-ordered, the caller holds it)."""
+    rows = [[t_in.data_ptr(), t_out.data_ptr(), r, c, ldi, ro, co, ldo, int(tr), int(of)]
+            for (t_in, t_out, r, c, ldi, ro, co, ldo, tr, of) in jobs]
+    host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+    tab = host.to(device, non_blocking=True)
+    biggest = max(j[5] * j[6] for j in jobs)
+    call("pp_cast_pad_2d_multi", C.c_void_p(tab.data_ptr()), len(jobs), max(1, min(64, (biggest + 2047) // 2048)), _s())
+    return tab, host
 
 
 def copy_2d_f32(inp, ld_in, out, ld_out, rows, cols):

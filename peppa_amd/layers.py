@@ -262,6 +262,34 @@ def prep_linear(w, need_dgrad=True):
     return wf, wt
 
 
+class CastBatch:
+    """Weight-operand preparation for many Linear layers in ONE launch (pp_cast_pad_2d_multi)."""
+
+    def __init__(self):
+        self.jobs = []
+        self._keep = None
+
+    def cast(self, w, out, rows, cols, ld_in, rows_out, cols_out, ld_out, transpose=False, out_f32=False):
+        self.jobs.append((w, out, rows, cols, ld_in, rows_out, cols_out, ld_out, transpose, out_f32))
+
+    def linear(self, w, need_dgrad=True):
+        """Same operands as prep_linear: (bf16 [N][Kp], bf16 transposed [K][Np] or None)."""
+        N, K = w.shape
+        Kp, Np = cpad(K), cpad(N)
+        wf = empty((N, Kp), bf16, w)
+        self.cast(w, wf, N, K, K, N, Kp, Kp)
+        wt = None
+        if need_dgrad:
+            wt = empty((K, Np), bf16, w)
+            self.cast(w, wt, K, N, K, K, Np, Np, transpose=True)
+        return wf, wt
+
+    def run(self, device):
+        if self.jobs:
+            self._keep = H.cast_pad_2d_multi(self.jobs, device)
+        self.jobs = []
+
+
 def linear_fwd(x, M, wf, N, *, bias=None, act=H.ACT_NONE, residual=None, pre=None, out=None, out_f32=False):
     """x bf16 [M][Kp] -> y [M][Np]."""
     Kp = wf.shape[1]
