@@ -258,9 +258,17 @@ def _prep_encoder_weights(enc, save):
     return w, batch
 
 
+FUSED_ATTENTION = True   # one launch per direction (pp_attention_*) when T <= 128; False: batched GEMMs + softmax + transposes
+
+
 def _attention_fwd(qkv, B, T, Tp, scale, save, drop=(0.0, 0)):
-    """qkv bf16 [B*T][2304] -> ctx bf16 [B*T][768]; returns saved P (before attention dropout)."""
+    """qkv bf16 [B*T][2304] -> ctx bf16 [B*T][768]; returns saved P (before attention dropout), or None (fused path:
+    the backward recomputes the probabilities)."""
     Hn, Dh, D3 = NUM_HEADS, 64, 2304
+    if FUSED_ATTENTION and T <= 128:
+        ctx = L.empty((B * T, 768), bf16, qkv)
+        H.attention_fwd(qkv, B, T, Hn, scale, drop[0], drop[1], ctx)
+        return ctx, None
     nb = B * Hn
     S = L.empty((nb, T, Tp), f32, qkv)
     q, k, v = qkv, qkv[:, 768:], qkv[:, 1536:]   # column views (pointer offsets only)
@@ -283,6 +291,10 @@ def _attention_fwd(qkv, B, T, Tp, scale, save, drop=(0.0, 0)):
 def _attention_bwd(dctx, qkv, P, B, T, Tp, scale, drop=(0.0, 0)):
     """-> dqkv bf16 [B*T][2304]."""
     Hn, Dh, D3 = NUM_HEADS, 64, 2304
+    if P is None:   # forward ran fused
+        dqkv = L.empty((B * T, D3), bf16, qkv)
+        H.attention_bwd(qkv, dctx, B, T, Hn, scale, drop[0], drop[1], dqkv)
+        return dqkv
     nb = B * Hn
     q, k, v = qkv, qkv[:, 768:], qkv[:, 1536:]
     dqkv = L.empty((B * T, D3), bf16, qkv)

@@ -290,6 +290,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, ws=None)
          _p(dgamma, f32), _p(dbeta, f32), rows, D, _p(ws, f32), 0 if ws is None else ws.shape[0], _s())
 
 
+def attention_fwd(qkv, B, T, heads, scale, p, seed, ctx):
+    call("pp_attention_fwd", _p(qkv, bf16), B, T, heads, float(scale), float(p), int(seed) & 0xffffffff, _p(ctx, bf16), _s())
+
+
+def attention_bwd(qkv, dctx, B, T, heads, scale, p, seed, dqkv):
+    call("pp_attention_bwd", _p(qkv, bf16), _p(dctx, bf16), B, T, heads, float(scale), float(p), int(seed) & 0xffffffff,
+         _p(dqkv, bf16), _s())
+
+
 def softmax_fwd(S, lds, P, ldp, nb, T, scale):
     call("pp_softmax_fwd", _p(S, f32), lds, _p(P, bf16), ldp, nb, T, scale, _s())
 

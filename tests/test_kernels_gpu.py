@@ -821,3 +821,41 @@ def test_recall_metrics_on_device(golden_dir):
     torch.manual_seed(5)
     t = M.resampled_recall_at_1_to_n(X.to(DEV), Y.to(DEV), size=100, n_samples=3, N=4)
     assert t.shape == (3, 5, 100) and (t[:, 0] == 0).all() and (t[:, 1:].diff(dim=1) >= 0).all()
+
+
+@pytest.mark.parametrize("B,T,p", [(3, 114, 0.0), (2, 49, 0.1), (2, 128, 0.1), (1, 7, 0.0)])
+def test_fused_attention_matches_unfused_and_torch(B, T, p):
+    """pp_attention_fwd / _bwd (one workgroup per clip and head, scores in MFMA accumulators, probabilities recomputed in
+    the backward) against the unfused HIP path (same dropout stream) and, without dropout, against fp32 torch."""
+    from peppa_amd import audio as A
+    g = torch.Generator().manual_seed(B * 100 + T)
+    M, Tp = B * T, L.cpad(T)
+    qkv = (0.5 * torch.randn(M, 2304, generator=g)).to(torch.bfloat16).to(DEV)
+    dctx = torch.randn(M, 768, generator=g).to(torch.bfloat16).to(DEV)
+    scale, drop = 0.125, (p, 12345)
+    outs = []
+    try:
+        for fused in (False, True):
+            A.FUSED_ATTENTION = fused
+            ctx, P = A._attention_fwd(qkv, B, T, Tp, scale, True, drop)
+            dqkv = A._attention_bwd(dctx, qkv, P, B, T, Tp, scale, drop)
+            torch.cuda.synchronize()
+            assert (P is None) == fused
+            outs.append((ctx.float().cpu(), dqkv.float().cpu()))
+    finally:
+        A.FUSED_ATTENTION = True
+    for a, b, name in zip(outs[0], outs[1], ("ctx", "dqkv")):
+        scale_ = a.abs().max().item()
+        assert (a - b).abs().max().item() <= 2.0 ** -6 * scale_, f"{name}: fused differs from unfused by {(a - b).abs().max().item()}"
+        assert rel_l2(b, a) <= 6e-3, f"{name}: {rel_l2(b, a)}"
+    if p == 0.0:
+        x = qkv.float().cpu().view(B, T, 3, 12, 64).requires_grad_()
+        q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)   # (B, 12, T, 64)
+        ctx_ref = (torch.softmax(scale * q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(M, 768)
+        ctx_ref.backward(dctx.float().cpu())
+        close(outs[1][0], ctx_ref, name="fused ctx vs torch")
+        close(outs[1][1], x.grad.reshape(M, 2304), name="fused dqkv vs torch")
+
+
+def rel_l2(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()

@@ -40,3 +40,13 @@ for name, M, C in [("l1 mid 144", 3211264, 144), ("l1 out 64", 3211264, 64), ("l
     t_bwd = timeit(bnb)
     print(f"{name:12s} M={M} C={Cp}: fwd finalize+apply {t_apply*1e6:7.1f} us ({4*elems/t_apply/1e12:.2f} TB/s of y->z) | "
           f"bwd reduce+finalize+apply {t_bwd*1e6:7.1f} us ({10*elems/t_bwd/1e12:.2f} TB/s of 10 B/elem)", flush=True)
+    # the backward passes one by one
+    nb = min(2048, (M + 63) // 64)
+    pb = torch.empty(nb, 2, Cp, device=dev)
+    coef = torch.zeros(3, Cp, device=dev)
+    dy = torch.empty_like(y)
+    tr = timeit(lambda: H.bn_bwd_reduce(dz, y, None, sv.mean, sv.rstd, sv.scale, sv.shift, True, pb, nb, M, Cp))
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    tf = timeit(lambda: H.bn_bwd_finalize(pb, nb, sv.count, sv.C, Cp, bn.weight, sv.rstd, dg, db, coef))
+    ta = timeit(lambda: H.bn_bwd_apply(dz, y, None, sv.mean, sv.rstd, coef, sv.scale, sv.shift, True, dy, None, M, Cp))
+    print(f"             reduce {tr*1e6:7.1f} us ({4*elems/tr/1e12:.2f} TB/s) | finalize {tf*1e6:6.1f} us | apply {ta*1e6:7.1f} us ({6*elems/ta/1e12:.2f} TB/s)", flush=True)

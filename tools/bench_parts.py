@@ -38,3 +38,15 @@ def issue_time(fn, n=5):
         t0 = time.perf_counter(); fn(); tot += time.perf_counter() - t0; torch.cuda.synchronize()
     return tot / n * 1e3
 print(f"host issue time: video {issue_time(video):.1f} ms | audio {issue_time(audio):.1f} ms | full {issue_time(full):.1f} ms")
+if os.environ.get("AB_WGRAD_OVERLAP"):
+    from peppa_amd import video as PV
+    for flag in (True, False, True, False):
+        PV.OVERLAP_WGRAD = flag
+        print(f"overlap_wgrad={flag}: video fwd+bwd {t(video):.2f} ms | full step {t(full):.2f} ms")
+    PV.OVERLAP_WGRAD = True
+if os.environ.get("AB_FUSED_ATTENTION"):
+    from peppa_amd import audio as PA
+    for flag in (True, False, True, False):
+        PA.FUSED_ATTENTION = flag
+        print(f"fused_attention={flag}: audio fwd+bwd {t(audio):.2f} ms | full step {t(full, 8):.2f} ms")
+    PA.FUSED_ATTENTION = True
