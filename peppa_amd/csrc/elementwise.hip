@@ -82,15 +82,38 @@ __global__ void cast_pad_2d_kernel(const float* __restrict__ in, int rows, int c
 // the same, for a device table of jobs in one launch (blockIdx.y = job): the ~140 per-step weight casts of the audio
 // tower are 3-8 us launches each; as one launch they are a few
 struct CastItem { const float* in; void* out; long long rows, cols, ld_in, rows_out, cols_out, ld_out, transpose, out_f32; };
-__global__ void cast_pad_2d_multi_kernel(const CastItem* __restrict__ items) {
+__global__ __launch_bounds__(256) void cast_pad_2d_multi_kernel(const CastItem* __restrict__ items) {
+  // 32 x 32 output tiles through LDS, so that the transposing jobs read AND write whole rows
+  __shared__ float tile[32][33];
   const CastItem it = items[blockIdx.y];
-  const long long n = it.rows_out * it.cols_out;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / it.cols_out, c = i - r * it.cols_out;
-    float v = 0.f;
-    if (r < it.rows && c < it.cols) v = it.transpose ? it.in[c * it.ld_in + r] : it.in[r * it.ld_in + c];
-    if (it.out_f32) ((float*)it.out)[r * it.ld_out + c] = v;
-    else ((bfraw*)it.out)[r * it.ld_out + c] = f2bf(v);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8 threads
+  const long long tr = (it.rows_out + 31) / 32, tc = (it.cols_out + 31) / 32;
+  for (long long t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const long long r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+    if (it.transpose) {   // out[r][c] = in[c][r]: read rows of `in` (index c), columns r0 + tx
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long long c = c0 + ty + 8 * k, r = r0 + tx;
+        tile[ty + 8 * k][tx] = (r < it.rows && c < it.cols) ? it.in[c * it.ld_in + r] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long long r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < it.rows && c < it.cols) ? it.in[r * it.ld_in + c] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long r = r0 + ty + 8 * k, c = c0 + tx;
+      if (r < it.rows_out && c < it.cols_out) {
+        const float v = it.transpose ? tile[tx][ty + 8 * k] : tile[ty + 8 * k][tx];
+        if (it.out_f32) ((float*)it.out)[r * it.ld_out + c] = v;
+        else ((bfraw*)it.out)[r * it.ld_out + c] = f2bf(v);
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -632,13 +632,22 @@ int launch_ring(const pp_igemm_desc& d, hipStream_t s) {
   const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
 #define PP_LAUNCH_RING(MODE_, FULL_) \
   hipLaunchKernelGGL((igemm_kernel<WN, MODE_, FULL_, 8, true>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles)
-  switch (d.g.mode) {   // (fused epilogues: dense only -- the conv forms of the kernel would spill)
+  switch (d.g.mode) {   // (fused epilogues: dense, and conv-forward at 128 columns -- the other conv forms would spill)
     case PP_DENSE:
       if (full) PP_LAUNCH_RING(PP_DENSE, true);
       else PP_LAUNCH_RING(PP_DENSE, false);
       break;
-    case PP_CONV_FWD: PP_LAUNCH_RING(PP_CONV_FWD, false); break;
-    case PP_CONV_DGRAD: PP_LAUNCH_RING(PP_CONV_DGRAD, false); break;
+    case PP_CONV_FWD:
+      if constexpr (WN == 8) {
+        if (full) { PP_LAUNCH_RING(PP_CONV_FWD, true); break; }
+      }
+      if (full) { pp_set_error("pp_igemm: internal: fused conv epilogue on a ring tile without one"); return PP_ERR_INVALID; }
+      PP_LAUNCH_RING(PP_CONV_FWD, false);
+      break;
+    case PP_CONV_DGRAD:
+      if (full) { pp_set_error("pp_igemm: internal: fused conv epilogue on a ring tile without one"); return PP_ERR_INVALID; }
+      PP_LAUNCH_RING(PP_CONV_DGRAD, false);
+      break;
     default: pp_set_error("pp_igemm: bad gather mode %d", d.g.mode); return PP_ERR_INVALID;
   }
 #undef PP_LAUNCH_RING
@@ -710,13 +719,15 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   }
   const int n16 = (d.N + 15) / 16;
   const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
-  if (pp_opt_ring && !d.c_fp32 && d.nbatch == 1 && n16 > 4 && d.K >= 2 * BK && (!full || d.g.mode == PP_DENSE)) {
+  if (pp_opt_ring && !d.c_fp32 && d.nbatch == 1 && n16 > 4 && d.K >= 2 * BK) {
     // Ring tiles are 128 or 144 columns wide (whichever pads N less).  Narrow outputs (N <= 64) stay on the
     // register-staged kernel, which measured faster there; so do GEMMs too small to give every CU a 256-row tile.
+    // Fused epilogues (bias / activation / residual): dense at either width, conv-forward at 128 columns only.
     const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
     const int best = c9 <= c8 ? 9 : 8;
+    const bool epi_ok = !full || d.g.mode == PP_DENSE || (d.g.mode == PP_CONV_FWD && best == 8);
     const long long tiles = (((long long)d.M + 255) / 256) * ((n16 + best - 1) / best);
-    if (tiles >= pp_opt_ring) return best == 9 ? launch_ring<9>(d, s) : launch_ring<8>(d, s);
+    if (epi_ok && tiles >= pp_opt_ring) return best == 9 ? launch_ring<9>(d, s) : launch_ring<8>(d, s);
   }
   switch (pick_wn(n16)) {
     case 15: return launch_wn<15>(d, s);

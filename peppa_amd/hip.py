@@ -185,7 +185,7 @@ def cast_pad_2d_multi(jobs, device):
     host = torch.tensor(rows, dtype=torch.int64).pin_memory()
     tab = host.to(device, non_blocking=True)
     biggest = max(j[5] * j[6] for j in jobs)
-    call("pp_cast_pad_2d_multi", C.c_void_p(tab.data_ptr()), len(jobs), max(1, min(64, (biggest + 2047) // 2048)), _s())
+    call("pp_cast_pad_2d_multi", C.c_void_p(tab.data_ptr()), len(jobs), max(1, min(256, (biggest + 1023) // 1024)), _s())
     return tab, host
 
 
