@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=36800)
     ap.add_argument("--config", default=os.path.join(ROOT, "hparams_base.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="no HIP events inside the timed region (roofline: null)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     return ap.parse_args()
 
@@ -95,7 +96,7 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl")   # (no device_id: the eager communicator made every kernel of the step ~10 % slower)
 
     import yaml
     import pig.models
@@ -127,12 +128,12 @@ def main():
     H.PROFILE_STREAM = torch.cuda.current_stream()   # the video trunk's stream; the audio tower overlaps on a side stream
     for i in range(args.warmup):
         H.PROFILE.clear()
-        H.PROFILE_ONLY, H.PROFILE_ON = None, (i == args.warmup - 1)
+        H.PROFILE_ONLY, H.PROFILE_ON = None, (i == args.warmup - 1 and not args.no_roofline)
         step(i)
     dom = H.profile_summary()
     H.PROFILE.clear()
     H.PROFILE_ONLY = dom[3] if dom else None
-    H.PROFILE_ON = True
+    H.PROFILE_ON = not args.no_roofline
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

@@ -7,8 +7,8 @@ One process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI) or "g
     dV/dA and keeps its own rows.
   * `GradBuckets`: gradients are copied into a few large flat fp32 buckets (one per encoder, sized
     for 7 x 153 GB/s point-to-point xGMI links rather than for many small NVSwitch-style calls) and
-    all-reduced with SUM on a side stream as soon as a bucket is complete, overlapping the other
-    encoder's backward.  SUM, not mean: each rank's loss is already the global mean and its backward
+    all-reduced with SUM as soon as a bucket is complete (asynchronously, on RCCL's stream), overlapping
+    the other encoder's backward.  SUM, not mean: each rank's loss is already the global mean and its backward
     only covers the local clips ("all-gather gradient routing").
 BatchNorm uses per-rank statistics (documented deviation from a single-process N=512 batch).
 """
@@ -55,8 +55,9 @@ class GradBuckets:
 
     def __init__(self, named_groups, device):
         """named_groups: [(name, [params])]; params without grad at step time are skipped (zeros)."""
+        from .video import ensure_streams
+        ensure_streams(device)   # the towers' side streams must exist before RCCL creates its own (see there)
         self.buckets = []
-        self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         for name, params in named_groups:
             params = [p for p in params if p.requires_grad]
             total = sum(p.numel() for p in params)
@@ -88,17 +89,13 @@ class GradBuckets:
             self._launch(b)
 
     def _launch(self, b):
-        grads = [p.grad for p in b["params"]]
-        if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                torch._foreach_copy_(b["views"], grads)          # plumbing: pack
-                if is_dist():
-                    b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
-        else:
-            torch._foreach_copy_(b["views"], grads)
-            if is_dist():
-                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+        # On the stream the hook runs on (the tower's own): RCCL orders the collective after the work queued there and
+        # runs it on its internal stream, so the tower's remaining kernels and the other tower overlap it.  A dedicated
+        # stream for the packing cost 4 ms per step on one GPU: with the video, audio and weight-gradient streams it
+        # is the fifth, and HIP maps streams onto four hardware queues -- two streams then share one, in order.
+        torch._foreach_copy_(b["views"], [p.grad for p in b["params"]])          # plumbing: pack
+        if is_dist():
+            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):
         """Wait for the collectives and point every p.grad at its reduced bucket view.  Parameters that got no
@@ -120,8 +117,6 @@ class GradBuckets:
                     b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
             if b["work"] is not None:
                 b["work"].wait()
-        if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
         for b in self.buckets:
             for p, v, had in zip(b["params"], b["views"], b["had_grad"]):
                 if had:

@@ -395,9 +395,7 @@ class PeppaPig(_Base):
         if not (self._overlap and video.is_cuda):
             return self.encode_video(video), self.encode_audio(audio)
         main = torch.cuda.current_stream()
-        if self._side_stream is None or self._side_stream.device != video.device:
-            self._side_stream = torch.cuda.Stream(device=video.device)
-        side = self._side_stream
+        side = self._side_stream = V.tower_stream(video.device)
         side.wait_stream(main)                                   # (the inputs; not the video kernels issued next)
         video = prelaunch_video_trunk(self.video_encoder, video)  # long kernels first: the host runs ahead of them
         with torch.cuda.stream(side):

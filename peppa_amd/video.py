@@ -265,9 +265,37 @@ OVERLAP_WGRAD = True   # bench.py clears this for its isolated (one kernel at a 
 
 
 def _wgrad_stream(device):
+    device = torch.device(device)
     if device not in _WGRAD_STREAMS:
         _WGRAD_STREAMS[device] = torch.cuda.Stream(device=device)
     return _WGRAD_STREAMS[device]
+
+
+_TOWER_STREAMS = {}
+
+
+def tower_stream(device):
+    """Side stream of the audio tower (PeppaPig.encode_pair)."""
+    device = torch.device(device)
+    if device not in _TOWER_STREAMS:
+        _TOWER_STREAMS[device] = torch.cuda.Stream(device=device)
+    return _TOWER_STREAMS[device]
+
+
+def ensure_streams(device):
+    """Create the step's side streams NOW (weight-gradient stream, audio-tower stream) and touch each once.
+
+    ROCclr maps streams onto four hardware queues in creation order.  Created lazily, the weight-gradient stream comes
+    to life in the first backward pass -- after RCCL has made its own stream for the first all-gather -- and then shares
+    a hardware queue with a busy stream: +5 ms per step measured on one GPU (tools/probe/bench_dbg.py).  Data-parallel
+    entry points call this before the first collective."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return
+    for st in (_wgrad_stream(device), tower_stream(device)):
+        with torch.cuda.stream(st):
+            torch.zeros(8, device=device).add_(1)
+    torch.cuda.synchronize(device)
 
 
 def trunk_backward(tape, dz, grads, overlap_wgrad=True):
