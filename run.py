@@ -40,7 +40,9 @@ def main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from peppa_amd.video import ensure_streams
+        ensure_streams(f"cuda:{local_rank}")            # the step's side streams before RCCL creates its own
+        torch.distributed.init_process_group("nccl")    # lazy communicator: an eager one (device_id=) slows every kernel
     data = SyntheticPigData(config['data'], frames=args.frames, size=args.size, samples=args.samples,
                             steps_per_epoch=args.limit_train_batches or 100, device=f"cuda:{local_rank}")
     net = pig.models.PeppaPig(config).to(f"cuda:{local_rank}")
