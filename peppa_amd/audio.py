@@ -19,6 +19,7 @@ from torch import nn
 from . import hip as H
 from . import layers as L
 from .hip import bf16, f32
+from .dist import grad_dict
 
 CONV_SPEC = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
 NUM_HEADS = 12
@@ -536,7 +537,7 @@ class Wav2Vec2Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        model, grads = ctx.model, {}
+        model, grads = ctx.model, grad_dict()
         fe = model.feature_extractor
         dout = dout.contiguous().float()
         with torch.no_grad(), L.ZeroPool("audio", dout.device):

@@ -50,14 +50,44 @@ def gather_embeddings(V, A):
     return _GatherFn.apply(V, A)
 
 
+_ACTIVE = None   # the GradBuckets instance the towers hand their gradients to as they are produced
+
+
+class _PushDict(dict):
+    """`grads[param] = tensor` inside a tower's backward also hands the gradient to the bucket manager."""
+
+    def __init__(self, mgr):
+        super().__init__()
+        self._mgr = mgr
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        self._mgr.push(k, v)
+
+
+def grad_dict():
+    """Dictionary the towers' backward passes fill (param -> gradient).  Under data parallelism every assignment is an
+    early hand-off: a tower is ONE autograd node, so autograd itself would deliver all of its gradients in a burst at
+    the very end of the backward pass and no all-reduce could overlap it."""
+    if _ACTIVE is not None and is_dist():
+        return _PushDict(_ACTIVE)
+    return {}
+
+
 class GradBuckets:
-    """Flat gradient buckets with per-bucket asynchronous all-reduce (SUM)."""
+    """Flat gradient buckets with per-bucket asynchronous all-reduce (SUM).
+
+    A bucket is packed and reduced as soon as all of its gradients exist.  They arrive either early, from inside a
+    tower's backward (`push`, via grad_dict()), or through autograd's post-accumulate hooks (heads, and every parameter
+    while gradients are being accumulated over micro-batches)."""
 
     def __init__(self, named_groups, device):
         """named_groups: [(name, [params])]; params without grad at step time are skipped (zeros)."""
+        global _ACTIVE
         from .video import ensure_streams
         ensure_streams(device)   # the towers' side streams must exist before RCCL creates its own (see there)
         self.buckets = []
+        self.cuda = torch.device(device).type == "cuda"
         for name, params in named_groups:
             params = [p for p in params if p.requires_grad]
             total = sum(p.numel() for p in params)
@@ -66,7 +96,8 @@ class GradBuckets:
             for p in params:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-            self.buckets.append(dict(name=name, params=params, flat=flat, views=views, pending=0, work=None))
+            self.buckets.append(dict(name=name, params=params, flat=flat, views=views, pending=0, work=None,
+                                     pushed={}, events={}))
         self._hooks = []
         self._by_param = {}
         for b in self.buckets:
@@ -74,26 +105,56 @@ class GradBuckets:
                 self._by_param[p] = b
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.reset()
+        _ACTIVE = self
+
+    def close(self):
+        global _ACTIVE
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if _ACTIVE is self:
+            _ACTIVE = None
 
     def reset(self):
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["work"] = None
+            b["pushed"] = {}
+            b["events"] = {}
+
+    def push(self, p, g):
+        """Gradient `g` of parameter `p` is final for this backward pass (called on the stream that produces it)."""
+        b = self._by_param.get(p)
+        if b is None or g is None or p in b["pushed"] or p.grad is not None:
+            return   # not ours / already handed over / accumulating over micro-batches: the hook path takes it
+        b["pushed"][p] = g
+        if self.cuda:
+            b["events"][torch.cuda.current_stream()] = True   # (the set of producing streams)
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
 
     def _on_grad(self, p):
         if p.grad is None:   # autograd also runs the hook when a Function returned None for this parameter
             return           # (e.g. a layer skipped by LayerDrop): nothing arrived
         b = self._by_param[p]
+        if p in b["pushed"]:
+            return           # handed over early by its tower
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
 
     def _launch(self, b):
-        # On the stream the hook runs on (the tower's own): RCCL orders the collective after the work queued there and
-        # runs it on its internal stream, so the tower's remaining kernels and the other tower overlap it.  A dedicated
-        # stream for the packing cost 4 ms per step on one GPU: with the video, audio and weight-gradient streams it
-        # is the fifth, and HIP maps streams onto four hardware queues -- two streams then share one, in order.
-        torch._foreach_copy_(b["views"], [p.grad for p in b["params"]])          # plumbing: pack
+        # On the stream of the last arrival (a tower's own stream): RCCL orders the collective after the work queued
+        # there and runs it on its internal stream, so the remaining kernels of both towers overlap it.  (A dedicated
+        # packing stream cost 4 ms per step on one GPU -- see video.ensure_streams.)
+        if self.cuda:   # gradients produced on other streams: everything queued there so far comes first (one event
+            cur = torch.cuda.current_stream()   # per stream and bucket; per-gradient events cost 4 ms per step)
+            for st in b["events"]:
+                if st != cur:
+                    cur.wait_stream(st)
+        srcs = [b["pushed"][p] if p in b["pushed"] else p.grad for p in b["params"]]
+        torch._foreach_copy_(b["views"], srcs)          # plumbing: pack
         if is_dist():
             b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
 
@@ -125,9 +186,9 @@ class GradBuckets:
 
 
 def default_buckets(net, device):
-    """Bucket layout for PeppaPig: the video tower, the wav2vec2 feature extractor, one bucket per transformer
-    layer (so LayerDrop leaves whole buckets empty instead of forcing a late, unoverlapped reduce) and the rest of
-    the audio tower.  24-130 MB each: large enough for RCCL's multi-ring bandwidth over the 7 xGMI links."""
+    """Bucket layout for PeppaPig: the video tower by stage, the wav2vec2 feature extractor, one bucket per
+    transformer layer (so LayerDrop leaves whole buckets empty instead of forcing a late, unoverlapped reduce) and the
+    rest of the audio tower.  Mostly 17-100 MB: large enough for RCCL's multi-ring bandwidth over the 7 xGMI links."""
     audio = net.audio_encoder
     groups = []
     enc = getattr(audio.audio, "encoder", None)
@@ -141,6 +202,17 @@ def default_buckets(net, device):
     groups.append(("audio.feature_extractor", fe))
     seen = layer_params | set(fe)
     groups.append(("audio.rest", [p for p in audio.parameters() if p not in seen]))
-    vname = "image.fc" if hasattr(net.video_encoder, "image") else "video.fc"
-    groups.append(("video", [p for n, p in net.video_encoder.named_parameters() if not n.startswith(vname)]))
+    # video tower by stage, last stage first in the backward pass: layer4 holds three quarters of its parameters and
+    # its gradients exist after the first couple of milliseconds of the backward pass
+    trunk = "image" if hasattr(net.video_encoder, "image") else "video"
+    stages = {}
+    for n, p in net.video_encoder.named_parameters():
+        if n.startswith(trunk + ".fc"):
+            continue   # torchvision's classifier: frozen / unused
+        parts = n.split(".")
+        key = parts[1] if parts[0] == trunk and parts[1].startswith("layer") else ("stem" if parts[0] == trunk else "head")
+        key = "layer1" if key == "stem" else key           # (stem + layer1: 0.7 M parameters together)
+        stages.setdefault(key, []).append(p)
+    for key in sorted(stages):
+        groups.append((f"video.{key}", stages[key]))
     return GradBuckets([(n, ps) for n, ps in groups if any(p.requires_grad for p in ps)], device)

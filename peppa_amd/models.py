@@ -15,7 +15,7 @@ from .loss import TripletLoss
 from . import metrics as _metrics
 from . import optimization as opt
 from .data import ClipBatch
-from .dist import gather_embeddings
+from .dist import gather_embeddings, grad_dict
 from .triplet import TripletBatch as EmbeddingTripletBatch, score_triplets
 from .transforms import SwapCT  # noqa: F401  (API surface)
 
@@ -257,7 +257,7 @@ class VideoTrunkFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         B, Tn, HW, Cp = ctx.dims
-        grads = {}
+        grads = grad_dict()
         with torch.no_grad():
             dz = torch.empty(B * Tn * HW, Cp, dtype=bf16, device=dout.device)
             H.spatial_mean_bwd(dout.contiguous().float(), dz, B, Tn, HW, 512, Cp)
