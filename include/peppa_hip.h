@@ -23,7 +23,14 @@ enum pp_act { PP_ACT_NONE = 0, PP_ACT_GELU = 1, PP_ACT_RELU = 2 };
 enum pp_gather_mode { PP_DENSE = 0, PP_CONV_FWD = 1, PP_CONV_DGRAD = 2 };
 
 int pp_version(void);
-/* tuning switches (process-wide): "xcd_remap_igemm", "xcd_remap_wgrad" (0/1) */
+/* tuning switches (process-wide; also PEPPA_HIP_OPTIONS="name=value,..." through the Python loader):
+ *   "xcd_remap_igemm", "xcd_remap_wgrad"  0/1   XCD-contiguous tile order
+ *   "persistent_igemm"                    0/1   persistent workgroups with cross-tile prefetch (plain epilogues)
+ *   "ring_igemm"   n   LDS-DMA ring GEMM once there are >= n 256-row tiles (0 = never; default 128)
+ *   "win_igemm"    n   window kernel for (1,3,3) stride-1 convs, forward / data gradient, once M >= n (default 1024)
+ *   "sw_wgrad"     n   sliding-window weight gradients ((1,3,3) and (3,1,1) stride-1 convs) once M >= n (default 4096;
+ *                      1 also takes shapes the (3,1,1) kernel would decline as not worth it)
+ *   "ring_wgrad"   n   LDS-DMA ring variant of the generic weight gradient once M >= n (default 0 = never) */
 int pp_set_option(const char* name, int value);
 const char* pp_last_error(void);
 
