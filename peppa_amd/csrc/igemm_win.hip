@@ -17,13 +17,13 @@
 #include <type_traits>
 
 extern int pp_opt_xcd_remap_igemm;
+extern int pp_opt_win_tall;
 
 namespace {
 
 constexpr int BK = 64;
-constexpr int NW = 8, NT = 64 * NW, BM = 32 * NW;
+constexpr int NW = 8, NT = 64 * NW;
 constexpr int HALO = 64;                      // rows kept on either side of the tile (>= W + 1)
-constexpr int WROWS = BM + 2 * HALO;
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -65,9 +65,14 @@ struct WinArgs {
   int N, b_rows, ldb, ldc, ldr, ldstat;
 };
 
-template <int WN, int CC, bool RES>
+// MT = 16-row tiles per wave (2: 256-row workgroup tile; 4: 512 rows -- narrow outputs, where a weight fragment would
+// otherwise feed only two MFMAs per load and the per-K-step bookkeeping outweighs the matrix work).
+// NBS = weight ring slots (3: two K-steps in flight; 2, where LDS is short: one).
+template <int WN, int CC, bool RES, int MT, int NBS>
 __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap) {
+  constexpr int BM = 16 * MT * NW;
+  constexpr int WROWS = BM + 2 * HALO;
   constexpr int BN = 16 * WN;
   constexpr int B_BYTES = BN * 128;
   constexpr int XS = CC == 64 ? 128 : CC * 2 + 16;            // window row stride; 128-byte rows are XOR-swizzled
@@ -78,16 +83,17 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   constexpr int NBI = (BN * 8 + NT - 1) / NT;                 // weight pieces per wave and K-step (last one maybe absent)
   constexpr int KC = 9 * CC;                                  // flat K of one channel chunk: (tap, channel)
   constexpr int NKC = (KC + BK - 1) / BK;                     // K-steps per chunk
-  static_assert(NKC >= NWP, "one window piece per K-step must cover a phase");
+  constexpr int PPK = (NWP + NKC - 1) / NKC;                  // window pieces issued per K-step
+  static_assert(NBS == 2 || NBS == 3, "weight ring");
   constexpr int STG_STRIDE = BN * 2 + 16;
   constexpr int STG_BYTES = NW * 16 * STG_STRIDE;
   constexpr int STAT_BYTES = NW * BN * 2 * 4;
   static_assert(STG_BYTES <= WIN_BYTES && STAT_BYTES <= B_BYTES, "the epilogue stages in a window buffer / weight slot");
-  constexpr int SMEM = 2 * WIN_BYTES + 3 * B_BYTES + 256 + 64;
+  constexpr int SMEM = 2 * WIN_BYTES + NBS * B_BYTES + 256 + 64;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];   // one LDS object (see igemm.hip)
   unsigned char* const bring = smem + 2 * WIN_BYTES;
-  unsigned char* const zrow = smem + 2 * WIN_BYTES + 3 * B_BYTES;      // 256 zero bytes
+  unsigned char* const zrow = smem + 2 * WIN_BYTES + NBS * B_BYTES;    // 256 zero bytes
   int* const lut = (int*)(zrow + 256);                                 // row offset of each tap
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
 
   // ---- per-tile state -------------------------------------------------------------------------------------------
   int mb = 0, nb = 0;
-  unsigned vmask[2];     // bit t: tap t of fragment row (wave * 32 + mt * 16 + fr) lies inside the image
+  unsigned vmask[MT];    // bit t: tap t of fragment row (wave * 16 MT + mt * 16 + fr) lies inside the image
   auto setup_tile = [&](const int tile) __attribute__((always_inline)) {
     nb = tile % nblk_n;
     mb = tile / nblk_n;
@@ -178,8 +184,8 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       bbase[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : OOB;
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int m = mb * BM + wave * 32 + mt * 16 + fr;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mb * BM + wave * (16 * MT) + mt * 16 + fr;
       const uint32_t q1 = fdiv((uint32_t)m, g.dW_);
       const int w = m - (int)q1 * g.W;
       const int h = (int)q1 - (int)fdiv(q1, g.dH_) * g.H;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     }
   };
 
-  f32x4 acc[2][WN];
+  f32x4 acc[MT][WN];
   // one 64-deep K-step of chunk-flat K: lane's two k-octets (ks * 4 + fq) have their own (tap, channel)
   int tapA[2], cA[2];
   auto reset_a_cursor = [&]() __attribute__((always_inline)) {
@@ -204,17 +210,15 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       cA[ks] = kf - tapA[ks] * CC;
     }
   };
-  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
-  const unsigned zaddr = lds0 + (unsigned)(2 * WIN_BYTES + 3 * B_BYTES) + (unsigned)(fr * 16);
   auto compute = [&](const unsigned char* win, const unsigned char* bslot) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int tap = tapA[ks], c = cA[ks];
       const int roff = lut[tap < 9 ? tap : 0];
-      bf16x8 af[2];
+      bf16x8 af[MT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int wrow = wave * 32 + mt * 16 + fr + HALO + roff;
+      for (int mt = 0; mt < MT; ++mt) {
+        const int wrow = wave * (16 * MT) + mt * 16 + fr + HALO + roff;
         const int col = CC == 64 ? (((c >> 3) ^ swz(wrow)) << 4) : c * 2;
         const bool ok = ((vmask[mt] >> tap) & 1u) != 0u;    // (tap >= 9, the K tail, has no bit set)
         const unsigned char* a = ok ? win + wrow * XS + col : zrow + fr * 16;
@@ -224,8 +228,8 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const bf16x8 bfm = *(const bf16x8*)(bslot + (j * 16 + fr) * 128 + fsw);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfm, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfm, acc[1][j], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfm, acc[mt][j], 0, 0, 0);
       }
       cA[ks] += BK;
       while (cA[ks] >= CC) { cA[ks] -= CC; ++tapA[ks]; }
@@ -235,11 +239,11 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   // ---- epilogue (plain bf16 store, optional residual add, optional BatchNorm column statistics); igemm.hip's ------
   const int ncols_store = (p.N + 7) & ~7;
   auto epilogue = [&](const int mb_e, const int nb_e, unsigned char* const ebuf, unsigned char* const sbuf) __attribute__((always_inline)) {
-    const int m_wave = mb_e * BM + wave * 32;
+    const int m_wave = mb_e * BM + wave * (16 * MT);
     unsigned char* stg = ebuf + wave * 16 * STG_STRIDE;
     unsigned char* stg_w = stg + (fq * 4) * STG_STRIDE + fr * 2;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -273,13 +277,13 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     }
-    if (p.colstats) {   // per-column sum / sum of squares per 128 output rows, deterministic (igemm.hip)
+    if (MT == 2 && p.colstats) {   // per-column sum / sum of squares per 128 output rows, deterministic (igemm.hip)
       float* statbuf = (float*)sbuf;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < (MT == 2 ? 2 : 0); ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = acc[mt][j][r];
@@ -329,12 +333,13 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   for (int k = 0; k < NWP; ++k) dma_window_piece(k, smem, mb * BM, 0);
   reset_b_cursor();
   dma_weights(bring);
-  if (S > 1) dma_weights(bring + B_BYTES);
+  if (NBS == 3 && S > 1) dma_weights(bring + B_BYTES);
   int last_batch = 0;                 // DMA instructions this wave issued in the previous iteration
   bool drain = true;                  // first step of a tile: wait for everything (epilogue stores included)
+  auto next_slot = [&](int sl) __attribute__((always_inline)) { return sl + 1 == NBS ? 0 : sl + 1; };
   while (true) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int next_tile = tile_index(it + 1);
@@ -350,34 +355,44 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       unsigned char* const win = smem + wsel * WIN_BYTES;
       unsigned char* const nwin = smem + (wsel ^ 1) * WIN_BYTES;
       for (int j = 0; j < NKC; ++j, ++s) {
-        wait_vmcnt_dyn(drain ? 0 : last_batch);
+        // three slots: everything but the batch of the previous iteration (the weights of step s + 1) must have landed;
+        // two slots: that batch IS the weights of this step
+        wait_vmcnt_dyn((drain || NBS == 2) ? 0 : last_batch);
         drain = false;
         __builtin_amdgcn_s_barrier();
         int batch = 0;
-        if (s + 2 < S) {
-          dma_weights(bring + (bsl >= 1 ? bsl - 1 : 2) * B_BYTES);
+        if (s + (NBS - 1) < S) {
+          dma_weights(bring + (NBS == 3 ? (bsl >= 1 ? bsl - 1 : 2) : (bsl ^ 1)) * B_BYTES);
           batch += nB;
         }
-        if (have_next && j < NWP) {
-          dma_window_piece(j, nwin, nm0, nchunk_i);
-          batch += (wave + NW * j < WPIECES) ? 1 : 0;
+        if (have_next) {
+#pragma unroll
+          for (int q = 0; q < PPK; ++q) {
+            const int k = j * PPK + q;
+            if (k < NWP) {
+              dma_window_piece(k, nwin, nm0, nchunk_i);
+              batch += (wave + NW * k < WPIECES) ? 1 : 0;
+            }
+          }
         }
         last_batch = batch;
         compute(win, bring + bsl * B_BYTES);
-        bsl = bsl == 2 ? 0 : bsl + 1;
+        bsl = next_slot(bsl);
       }
       wsel ^= 1;
     }
     const int mb_done = mb, nb_done = nb;
     unsigned char* const ebuf = smem + (wsel ^ 1) * WIN_BYTES;   // the window just consumed stages the output
-    unsigned char* const sbuf = bring + (bsl == 0 ? 2 : bsl - 1) * B_BYTES;   // ... the weight slot just consumed the statistics
+    unsigned char* const sbuf = bring + (bsl == 0 ? NBS - 1 : bsl - 1) * B_BYTES;   // ... the weight slot just consumed the statistics
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                               // every wave is done reading it
-    if (next_tile >= 0) {                                       // the next tile's first two weight steps fly under the epilogue
+    if (next_tile >= 0) {                                       // the next tile's first weight steps fly under the epilogue
       setup_tile(next_tile);
       reset_b_cursor();
+      // (two slots: the slot just consumed holds the statistics during the epilogue, so only the other one is refilled:
+      // it is the slot of step 0 of the next tile because bsl already points past the consumed one)
       dma_weights(bring + bsl * B_BYTES);
-      if (S > 1) dma_weights(bring + (bsl == 2 ? 0 : bsl + 1) * B_BYTES);
+      if (NBS == 3 && S > 1) dma_weights(bring + next_slot(bsl) * B_BYTES);
     }
     epilogue(mb_done, nb_done, ebuf, sbuf);
     if (next_tile < 0) break;
@@ -387,9 +402,9 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   }
 }
 
-template <int WN, int CC>
+template <int WN, int CC, int MT, int NBS>
 int launch_win(const pp_igemm_desc& d, hipStream_t s) {
-  constexpr int BN = 16 * WN;
+  constexpr int BN = 16 * WN, BM = 16 * MT * NW;
   const pp_gather& gg = d.g;
   WinGeom g;
   g.W = gg.Gw; g.H = gg.Gh; g.M = d.M; g.cstride = gg.cstride; g.cg = gg.cg;
@@ -406,8 +421,8 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < 256 ? ntiles : 256;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
-  if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
-  else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+  if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+  else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -428,11 +443,16 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
   const int n16 = (d.N + 15) / 16;
   // tile widths: 64 columns (narrow outputs) or 128 / 144 (whichever pads N less)
   if (g.cg % 64 == 0) {
-    if (n16 <= 4) return launch_win<4, 64>(d, s);
+    if (n16 <= 4) return launch_win<4, 64, 2, 3>(d, s);
     const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
-    return c9 <= c8 ? launch_win<9, 64>(d, s) : launch_win<8, 64>(d, s);
+    return c9 <= c8 ? launch_win<9, 64, 2, 3>(d, s) : launch_win<8, 64, 2, 3>(d, s);
   }
-  if (n16 <= 4) return launch_win<4, 48>(d, s);
+  if (n16 <= 4) {
+    // narrow output from 48-channel chunks (the layer-1 data gradient): 512-row tiles, four row tiles per wave, when
+    // there are enough rows to give every CU a few of them and no statistics are asked for
+    if (pp_opt_win_tall && !d.colstats && (pp_opt_win_tall == 2 || (long long)d.M >= 512LL * 256 * 2)) return launch_win<4, 48, 4, 2>(d, s);   // (2 = forced: tests)
+    return launch_win<4, 48, 2, 3>(d, s);
+  }
   const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
-  return c9 <= c8 ? launch_win<9, 48>(d, s) : launch_win<8, 48>(d, s);
+  return c9 <= c8 ? launch_win<9, 48, 2, 3>(d, s) : launch_win<8, 48, 2, 3>(d, s);
 }

@@ -720,8 +720,10 @@ def test_window_igemm_matches_gather_igemm(case):
     wf, wd = L.prep_conv_weights(w, geom)
     outs = []
     try:
-        for win in (0, 1):
+        # gather kernel; window kernel with 256-row tiles; window kernel with the 512-row tile forced where it exists
+        for win, tall in ((0, 0), (1, 0), (1, 2)):
             H.set_option("win_igemm", win)
+            H.set_option("win_tall", tall)
             y, st = L.conv_fwd(x, geom, wf, stats=True)
             dx = L.conv_dgrad(dy, geom, wd)
             dxr = L.conv_dgrad(dy, geom, wd, residual=res)
@@ -729,7 +731,9 @@ def test_window_igemm_matches_gather_igemm(case):
             outs.append((y.float(), st.clone(), dx.float(), dxr.float()))
     finally:
         H.set_option("win_igemm", H.WIN_IGEMM_DEFAULT)
-    for a, b, name in zip(outs[0], outs[1], ("fwd", "colstats", "dgrad", "dgrad + residual")):
+        H.set_option("win_tall", 1)
+    for a, b, name in list(zip(outs[0], outs[1], ("fwd", "colstats", "dgrad", "dgrad + residual"))) + \
+            list(zip(outs[0], outs[2], ("fwd (tall)", "colstats", "dgrad (tall)", "dgrad + residual (tall)"))):
         assert a.shape == b.shape, name
         scale = a.abs().max().item()
         err = (a - b).abs().max().item()
