@@ -666,6 +666,8 @@ def test_ring_wgrad_matches_register_staged(case):
     (128, 288, 2, 2, 14, 13),     # two channel blocks x two row blocks, odd width
     (64, 128, 1, 5, 9, 56),       # 128-row block (8 tiles), the layer-1 width
     (192, 230, 1, 2, 7, 7),       # ragged rows of dW (230 of 240), three channel blocks, tiny image (window >> image)
+    (64, 144, 1, 2, 3, 63),       # widest supported image (W + 1 = one 64-row step)
+    (64, 144, 1, 1, 5, 7),        # fewer rows than one step
 ])
 def test_sliding_window_wgrad_matches_generic(case):
     """Sliding-window weight gradient (X window in LDS, taps = row-shifted views + border masks) against the generic
@@ -703,6 +705,8 @@ def test_sliding_window_wgrad_matches_generic(case):
     (64, 230, 1, 3, 9, 56),       # dgrad from 240 padded channels (five 48-channel chunks); layer-1 width
     (256, 576, 1, 1, 14, 14),     # dgrad with 64-channel chunks (576 = 9 x 64); window >> image
     (64, 128, 3, 1, 7, 5),        # tiny images: most of every window lies in neighbouring images; ragged last tile
+    (144, 64, 1, 2, 3, 63),       # widest supported image (W + 1 = halo); fwd from 48-channel chunks to 64 columns
+    (64, 144, 1, 1, 4, 9),        # a single partial tile (36 rows)
 ])
 def test_window_igemm_matches_gather_igemm(case):
     """Window conv kernel (A halo window in LDS, taps = address offsets, zero row outside the image) against the
