@@ -127,6 +127,20 @@ int pp_fill_f32(float* p, float v, long long n, pp_stream_t s);
 int pp_video_normalize_ndhwc(const float* x, void* out, int B, int T, int H, int W,
                              const float* mean3 /* HOST */, const float* std3 /* HOST */, pp_stream_t s);
 
+/* ---- on-device collate: pig/data.py:60-78 featurize + collate, pig/util.py:19-33 pad_*_batch -------
+ * `items` is a DEVICE table of n clips, 2 x int64 each: {pointer, length}.  Byte/integer work, bit-exact.
+ * video: clip i = uint8 [T_i][H][W][3] frames as the decoder delivers them (length = T_i) ->
+ *        out fp32 [n][3][Tmax][H][W] = frame / 255 (float64 division rounded to fp32, as numpy + .float() do),
+ *        zero frames after T_i (pad_video_batch).  4-byte-aligned clips with H*W % 4 == 0 take the vector path. */
+int pp_collate_video_u8(const void* items, int n, int Tmax, int H, int W, float* out, pp_stream_t s);
+/* rows: clip i = `length` bytes -> out [n][row_bytes], zero after `length` (pad_audio_batch on fp32 samples, or the
+ *       uint8 batch [n][Tmax][H][W][3] that pp_video_normalize_u8_ndhwc reads) */
+int pp_collate_rows(const void* items, int n, long long row_bytes, void* out, pp_stream_t s);
+/* x uint8 [B][T][H][W][3] -> out bf16 [B][T][H][W][8]: /255, (x-mean)/std, channels 3..7 = 0; bit-identical to
+ * pp_collate_video_u8 followed by pp_video_normalize_ndhwc without the fp32 batch in between */
+int pp_video_normalize_u8_ndhwc(const void* x, void* out, int B, int T, int H, int W,
+                                const float* mean3 /* HOST */, const float* std3 /* HOST */, pp_stream_t s);
+
 /* MaxPool2d(3, 2, 1) of torchvision resnet18 (static ImageEncoder, pig/models.py:181-186) on channels-last
  * bf16 [N][H][W][Cp]; the backward routes each window's gradient to its first maximum (PyTorch's rule) */
 int pp_maxpool3x3s2_fwd(const void* x, void* y, int N, int H, int W, int Cp, pp_stream_t s);

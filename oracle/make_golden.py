@@ -117,7 +117,28 @@ def optim_fixture():
     np.savez(os.path.join(OUT, "ref_bertadam.npz"), **out)
 
 
+def collate_fixture():
+    """Ragged uint8 clips -> the padded fp32 batch, through the LIVE pig.util.pad_video_batch / pad_audio_batch.
+    `featurize` (pig/data.py:66-72) needs moviepy clips, so its frame arithmetic (frame / 255 -> float32, stack,
+    (T,H,W,C) -> (C,T,H,W)) is applied here to numpy frames with the same torch calls."""
+    rng = np.random.default_rng(5)
+    out = {}
+    for tag, (Hh, W), Ts, Ls in (("a", (8, 8), [3, 5, 1, 4], [100, 257, 1, 64]), ("b", (5, 7), [2, 1, 3], [33, 7, 50])):
+        frames = [rng.integers(0, 256, size=(t, Hh, W, 3), dtype=np.uint8) for t in Ts]
+        frames[0][0, 0, 0] = (0, 255, 128)
+        audio = [(0.1 * rng.standard_normal((1, l))).astype(np.float32) for l in Ls]
+        video = [torch.stack([torch.tensor(f / 255).float() for f in clip]).permute(3, 0, 1, 2) for clip in frames]
+        out[f"{tag}_frames"] = np.concatenate([f.reshape(-1) for f in frames])
+        out[f"{tag}_T"], out[f"{tag}_hw"] = np.array(Ts), np.array([Hh, W])
+        out[f"{tag}_audio"] = np.concatenate([a.reshape(-1) for a in audio])
+        out[f"{tag}_L"] = np.array(Ls)
+        out[f"{tag}_video_batch"] = pig.util.pad_video_batch(video).numpy()
+        out[f"{tag}_audio_batch"] = pig.util.pad_audio_batch([torch.tensor(a) for a in audio]).numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_collate.npz"), **out)
+
+
 if __name__ == "__main__":
+    collate_fixture()
     loss_fixture()
     metrics_fixture()
     optim_fixture()

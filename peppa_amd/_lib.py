@@ -67,6 +67,9 @@ SIGNATURES = {
     "pp_transpose_bf16": [P, L, I, P, L, I, I, I, I, I, L, L, I, P],
     "pp_fill_f32": [P, F, L, P],
     "pp_video_normalize_ndhwc": [P, P, I, I, I, I, C.POINTER(F), C.POINTER(F), P],
+    "pp_collate_video_u8": [P, I, I, I, I, P, P],
+    "pp_collate_rows": [P, I, L, P, P],
+    "pp_video_normalize_u8_ndhwc": [P, P, I, I, I, I, C.POINTER(F), C.POINTER(F), P],
     "pp_maxpool3x3s2_fwd": [P, P, I, I, I, I, P],
     "pp_maxpool3x3s2_bwd": [P, P, P, I, I, I, I, P],
     "pp_bn_finalize": [P, I, I, L, I, I, P, P, F, F, P, P, P, P, P, P, P, P],

@@ -209,6 +209,28 @@ def video_normalize_ndhwc(x, out, mean3, std3):
     call("pp_video_normalize_ndhwc", _p(x, f32), _p(out, bf16), B, T, H, W, m, sd, _s())
 
 
+def video_normalize_u8_ndhwc(x, out, mean3, std3):
+    """x uint8 (B,T,H,W,3) contiguous -> out bf16 [B*T*H*W][8]."""
+    B, T, H, W, c = x.shape
+    if c != 3 or x.dtype != torch.uint8 or not x.is_contiguous():
+        raise PeppaHipError(f"uint8 video must be contiguous (B,T,H,W,3), got {tuple(x.shape)} {x.dtype}")
+    m = (C.c_float * 3)(*mean3)
+    sd = (C.c_float * 3)(*std3)
+    call("pp_video_normalize_u8_ndhwc", x.data_ptr(), _p(out, bf16), B, T, H, W, m, sd, _s())
+
+
+def collate_video_u8(table, n, Tmax, H, W, out):
+    """table: int64 device tensor [n][2] = {frames pointer, T_i}; out fp32 (n,3,Tmax,H,W)."""
+    call("pp_collate_video_u8", table.data_ptr(), n, Tmax, H, W, _p(out, f32), _s())
+
+
+def collate_rows(table, n, row_bytes, out):
+    """table: int64 device tensor [n][2] = {pointer, bytes}; out: any contiguous tensor of n * row_bytes bytes."""
+    if out.numel() * out.element_size() != n * row_bytes or not out.is_contiguous():
+        raise PeppaHipError("collate_rows: output size mismatch")
+    call("pp_collate_rows", table.data_ptr(), n, row_bytes, out.data_ptr(), _s())
+
+
 def maxpool3x3s2_fwd(x, y, N, Hh, W, Cp):
     call("pp_maxpool3x3s2_fwd", _p(x, bf16), _p(y, bf16), N, Hh, W, Cp, _s())
 
@@ -418,6 +440,11 @@ def bertadam_step(tl, chunk_tensor, chunk_off, n_chunks, chunk, norms, lr, b1, b
 def make_tensor_list(ps, gs, ms, vs, device):
     """Device-resident pointer tables for pp_bertadam_step; returns (TensorList, keepalive)."""
     n = len(ps)
+    for group in (ps, gs, ms, vs):          # a host pointer in the table is a GPU memory fault, not an exception
+        for t in group:
+            if not t.is_cuda or t.dtype != f32 or not t.is_contiguous():
+                raise PeppaHipError("BertAdam tensors (parameters, gradients, next_m, next_v) must be contiguous "
+                                    f"fp32 on the GPU; got {t.dtype} on {t.device}")
     # pinned + non_blocking: a pageable copy would block the host until the whole backward pass has drained
     host = torch.tensor([[t.data_ptr() for t in ps], [t.data_ptr() for t in gs], [t.data_ptr() for t in ms],
                          [t.data_ptr() for t in vs], [t.numel() for t in ps]], dtype=torch.int64).pin_memory()

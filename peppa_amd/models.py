@@ -222,6 +222,16 @@ def _video_trunk_launch(enc, x, save):
     return out, tape, (B, Tn, HW, z.shape[1])
 
 
+def _trunk_input(x):
+    """fp32 (B,3,T,H,W) in [0,1] (the reference's batch), or the decoder's uint8 frames (B,T,H,W,3) as
+    data.collate_device(video_dtype=torch.uint8) leaves them: the stem's input kernel scales those itself."""
+    if x.dtype == torch.uint8:
+        if x.dim() != 5 or x.shape[-1] != 3:
+            raise ValueError(f"uint8 video batches are (B,T,H,W,3), got {tuple(x.shape)}")
+        return x.contiguous()
+    return x.contiguous().float()
+
+
 def prelaunch_video_trunk(enc, x):
     """Issue the trunk forward of `enc` (R3DEncoder / ImageEncoder) NOW, ahead of the autograd node that will own it.
 
@@ -230,7 +240,7 @@ def prelaunch_video_trunk(enc, x):
     the video autograd node is still created after the audio one -- so the backward pass also starts with video."""
     if not x.is_cuda:
         raise H.PeppaHipError("peppa_amd.video needs a CUDA/HIP tensor (no CPU fallback)")
-    xc = x.contiguous().float()
+    xc = _trunk_input(x)
     params = enc.video.trunk_parameters()
     save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     enc._prelaunched = (xc, save) + _video_trunk_launch(enc, xc, save)
@@ -244,7 +254,7 @@ class VideoTrunkFn(torch.autograd.Function):
     def forward(ctx, x, enc, want_grad, *params):
         if not x.is_cuda:
             raise H.PeppaHipError("peppa_amd.video needs a CUDA/HIP tensor (no CPU fallback)")
-        x = x.contiguous().float()
+        x = _trunk_input(x)
         save = want_grad and any(ctx.needs_input_grad)  # grad mode is always off inside Function.forward
         pre, enc._prelaunched = getattr(enc, "_prelaunched", None), None
         if pre is not None and pre[0] is x and pre[1] == save:
@@ -370,6 +380,12 @@ class PeppaPig(_Base):
     if pl is None:
         def log(self, name, value, **kwargs):
             self._logged[name] = value
+
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, hparams_file=None, strict=True, **kwargs):
+            """LightningModule.load_from_checkpoint for Lightning-1.4.9 files (pig/evaluation.py:52), without Lightning."""
+            from .checkpoint import load_model
+            return load_model(cls, checkpoint_path, map_location=map_location, hparams_file=hparams_file, strict=strict)
 
     def forward(self, batch):
         if isinstance(batch, TargetedTripletBatch):

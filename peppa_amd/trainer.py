@@ -16,32 +16,88 @@ class SyntheticPigData:
     """Synthetic ClipBatch stream with the shapes of the configured clips (the Peppa dataset and
     moviepy are not available offline)."""
 
-    def __init__(self, config, frames=16, size=112, samples=36800, steps_per_epoch=100, device="cuda"):
+    def __init__(self, config, frames=16, size=112, samples=36800, steps_per_epoch=100, device="cuda", val_batches=2):
         from .data import synthetic_batch
         self.batch = synthetic_batch(config["train"]["batch_size"], frames, size, samples).to(device)
-        self.steps_per_epoch = steps_per_epoch
+        self.steps_per_epoch, self.val_batches = steps_per_epoch, val_batches
 
     def train_dataloader(self):
         for _ in range(self.steps_per_epoch):
             yield self.batch
 
+    def val_dataloader(self, batches=None):
+        """The reference's four validation loaders (pig/data.py PigData.val_dataloader: main, narration, and the
+        two duration-matched triplet sets), as `batches` synthetic batches each; the triplet sets carry
+        durations drawn from three values so that `score_triplets` finds same-duration pairs."""
+        b = self.batch
+        batches = self.val_batches if batches is None else batches
+        n = b.video.shape[0]
+        dur = torch.tensor([2.0, 2.5, 3.0])[torch.arange(n) % 3]
+        trip = type(b)(b.video, b.audio, dur, dur)
+        return [[b] * batches, [b] * batches, [trip] * batches, [trip] * batches]
+
 
 class Trainer:
     def __init__(self, accumulate_grad_batches=1, limit_train_batches=None, max_steps=None, max_time_s=None,
-                 log_every=10, **ignored):
+                 log_every=10, max_epochs=1, limit_val_batches=None, callbacks=(), default_root_dir=None, **ignored):
         self.accumulate = max(1, int(accumulate_grad_batches))
-        self.limit_train_batches = limit_train_batches
+        self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.max_steps, self.max_time_s, self.log_every = max_steps, max_time_s, log_every
-        self.global_step = 0
+        self.max_epochs, self.callbacks = max_epochs, list(callbacks)
+        self.global_step = self.current_epoch = 0
+        self.callback_metrics = {}
+        self.default_root_dir = default_root_dir
+        if default_root_dir is not None:      # Lightning: {root}/lightning_logs/version_N/checkpoints
+            for cb in self.callbacks:
+                if getattr(cb, "dirpath", None) is None:
+                    cb.dirpath = f"{default_root_dir}/checkpoints"
+
+    def validate(self, net, data):
+        """One pass over the validation loaders -> `validation_epoch_end` -> logged metrics (pig/models.py:266-318)."""
+        was_training = net.training
+        net.eval()
+        outputs = []
+        with torch.no_grad():
+            for idx, loader in enumerate(data.val_dataloader()):
+                outs = []
+                for i, batch in enumerate(loader):
+                    if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                        break
+                    outs.append(net.validation_step(batch, i, dataloader_idx=idx))
+                outputs.append(outs)
+            net.validation_epoch_end(outputs)
+        net.train(was_training)
+        self.callback_metrics = dict(getattr(net, "_logged", {}))
+        return self.callback_metrics
 
     def fit(self, net, data):
-        optim = net.configure_optimizers()
+        optim = self.optimizer = net.configure_optimizers()
         buckets = None
         if is_dist():
             buckets = default_buckets(net, next(net.parameters()).device)
         net.train()
+        if self.default_root_dir is not None and (not is_dist() or torch.distributed.get_rank() == 0):
+            import os
+            import yaml
+            os.makedirs(self.default_root_dir, exist_ok=True)     # Lightning's logger: hparams.yaml beside checkpoints/
+            with open(os.path.join(self.default_root_dir, "hparams.yaml"), "w") as f:
+                yaml.safe_dump(dict(net.config), f)
         t0 = time.time()
         optim.zero_grad(set_to_none=True)
+        for epoch in range(self.max_epochs):
+            self.current_epoch = epoch
+            if self._train_epoch(net, data, optim, buckets, t0):
+                break
+            if hasattr(data, "val_dataloader") and self.callbacks:
+                metrics = self.validate(net, data)
+                rank0 = not is_dist() or torch.distributed.get_rank() == 0
+                for cb in self.callbacks:
+                    if rank0:
+                        cb.on_validation_end(net, optim, epoch, self.global_step, metrics)
+        return net
+
+    def _train_epoch(self, net, data, optim, buckets, t0):
+        """True when a step / time limit ended training."""
         for i, batch in enumerate(data.train_dataloader()):
             if self.limit_train_batches is not None and i >= self.limit_train_batches:
                 break
@@ -56,7 +112,7 @@ class Trainer:
                 if self.global_step % self.log_every == 0:
                     log.info("step %d loss %.5f (%.1f s)", self.global_step, float(loss), time.time() - t0)
             if self.max_steps is not None and self.global_step >= self.max_steps:
-                break
+                return True
             if self.max_time_s is not None and time.time() - t0 > self.max_time_s:
-                break
-        return net
+                return True
+        return False

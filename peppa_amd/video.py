@@ -203,11 +203,16 @@ class _Tape:
 
 
 def trunk_forward(net, x, norm_kind, training, save):
-    """x fp32 [B][3][T][H][W] -> (z bf16 [B*T'*H'*W'][512], (T',H',W'), tape)."""
-    B, _, T, Hh, W = x.shape
+    """x fp32 [B][3][T][H][W] (or uint8 [B][T][H][W][3]) -> (z bf16 [B*T'*H'*W'][512], (T',H',W'), tape)."""
     mean, std = VIDEO_STATS[norm_kind]
-    cur = L.empty((B * T * Hh * W, 8), bf16, x)
-    H.video_normalize_ndhwc(x, cur, mean, std)
+    if x.dtype == torch.uint8:               # padded decoder frames (B,T,H,W,3) from data.collate_device
+        B, T, Hh, W, _ = x.shape
+        cur = L.empty((B * T * Hh * W, 8), bf16, x)
+        H.video_normalize_u8_ndhwc(x, cur, mean, std)
+    else:
+        B, _, T, Hh, W = x.shape
+        cur = L.empty((B * T * Hh * W, 8), bf16, x)
+        H.video_normalize_ndhwc(x, cur, mean, std)
     return run_plan(net.units(), cur, (T, Hh, W), B, training, save, first=True)
 
 

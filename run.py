@@ -14,6 +14,7 @@ import yaml
 
 import pig.models
 from pig.execution import default_config
+from peppa_amd.checkpoint import ModelCheckpoint
 from peppa_amd.trainer import SyntheticPigData, Trainer
 
 
@@ -47,8 +48,14 @@ def main(args):
                             steps_per_epoch=args.limit_train_batches or 100, device=f"cuda:{local_rank}")
     net = pig.models.PeppaPig(config).to(f"cuda:{local_rank}")
     targs = dict(config['training']['trainer_args'])
+    # the reference's two checkpoint callbacks (run.py:32-55): best epoch by narration recall@10 and by triplet accuracy
+    callbacks = [ModelCheckpoint(monitor=monitor, mode='max', save_last=True, save_top_k=1,
+                                 filename="{epoch}-{" + monitor + ":.2f}")
+                 for monitor in ('valnarr_rec_fixed', 'valnarr_triplet')] if args.default_root_dir else []
     trainer = Trainer(accumulate_grad_batches=targs.get('accumulate_grad_batches', 1),
-                      limit_train_batches=args.limit_train_batches, max_time_s=2 * 24 * 3600)
+                      limit_train_batches=args.limit_train_batches, limit_val_batches=args.limit_val_batches,
+                      max_epochs=args.max_epochs, callbacks=callbacks, default_root_dir=args.default_root_dir,
+                      max_time_s=2 * 24 * 3600)
     trainer.fit(net, data)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -60,6 +67,9 @@ if __name__ == '__main__':
     parser.add_argument("--limit_train_batches", type=int, default=None)
     parser.add_argument("--limit_val_batches", type=int, default=None)
     parser.add_argument("--margin", type=float, default=None)
+    parser.add_argument("--max_epochs", type=int, default=1)
+    parser.add_argument("--default_root_dir", default=None,
+                        help="write Lightning-format checkpoints under {dir}/checkpoints after each validation pass")
     parser.add_argument("--random_init", action="store_true", default=True,
                         help="weights cannot be downloaded offline; build the same architectures from random init")
     parser.add_argument("--frames", type=int, default=16)

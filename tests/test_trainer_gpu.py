@@ -1,0 +1,58 @@
+"""run.py's loop end to end on the GPU: train a few steps, validate (recall@10 + triplet accuracy on the device),
+write Lightning-format checkpoints through the two ModelCheckpoint callbacks of run.py:32-55, reload the best one
+(pig/evaluation.py:42-53) and check it reproduces the embeddings bit for bit."""
+import copy
+import os
+
+import pytest
+import torch
+
+
+@pytest.mark.gpu
+def test_fit_validate_checkpoint_reload(tmp_path):
+    import pig.models
+    import pig.evaluation
+    from pig.execution import default_config
+    from peppa_amd.checkpoint import ModelCheckpoint, load_checkpoint, callback_states
+    from peppa_amd.trainer import SyntheticPigData, Trainer
+    cfg = copy.deepcopy(default_config)
+    cfg["video"]["pretrained"] = cfg["audio"]["pretrained"] = False
+    cfg["data"]["train"]["batch_size"] = 26
+    torch.manual_seed(0)
+    net = pig.models.PeppaPig(cfg).cuda()
+    data = SyntheticPigData(cfg["data"], frames=8, size=64, samples=16000, steps_per_epoch=2, val_batches=4)
+    root = str(tmp_path / "version_0")
+    callbacks = [ModelCheckpoint(monitor=m, mode="max", save_last=True, save_top_k=1, filename="{epoch}-{" + m + ":.2f}")
+                 for m in ("valnarr_rec_fixed", "valnarr_triplet")]
+    trainer = Trainer(max_epochs=2, callbacks=callbacks, default_root_dir=root)
+    trainer.fit(net, data)
+    assert trainer.global_step == 4
+    for name in ("val_loss", "valnarr_loss", "val_rec_fixed", "valnarr_rec_fixed", "val_triplet", "valnarr_triplet"):
+        assert name in trainer.callback_metrics, name
+    assert 0.0 <= float(trainer.callback_metrics["valnarr_rec_fixed"]) <= 1.0
+    assert 0.0 <= float(trainer.callback_metrics["valnarr_triplet"]) <= 1.0
+    files = sorted(os.listdir(os.path.join(root, "checkpoints")))
+    assert "last.ckpt" in files and os.path.exists(os.path.join(root, "hparams.yaml"))
+    assert any(f.startswith("epoch=") and "valnarr_rec_fixed=" in f for f in files)
+    assert any(f.startswith("epoch=") and "valnarr_triplet=" in f for f in files)
+    last = load_checkpoint(os.path.join(root, "checkpoints", "last.ckpt"))
+    assert last["global_step"] == 4 and last["epoch"] == 1 and callback_states(last)
+    opt_state = last["optimizer_states"][0]["state"]
+    assert all(set(st) >= {"step", "next_m", "next_v"} for st in opt_state.values()) and len(opt_state) > 100
+
+    best, path = pig.evaluation.load_best_model(root)
+    stored = load_checkpoint(path)["state_dict"]
+    for k, v in best.state_dict().items():
+        assert torch.equal(v.cpu(), stored[k]), k
+    best = best.cuda().eval()
+    twin = pig.models.PeppaPig.load_from_checkpoint(path).cuda().eval()
+    with torch.no_grad():
+        a = best.encode_video(data.batch.video[:4])
+        b = twin.encode_video(data.batch.video[:4])
+        c = best.encode_audio(data.batch.audio[:4])
+        d = twin.encode_audio(data.batch.audio[:4])
+    assert torch.equal(a, b) and torch.isfinite(a).all() and torch.isfinite(c).all()
+    assert torch.allclose(c, d, atol=1e-3)        # the audio tower's GroupNorm statistics use float atomics
+    # saving must not disturb the live optimizer state (it is copied to the host, never moved there)
+    for st in trainer.optimizer.state.values():
+        assert st["next_m"].is_cuda and st["next_v"].is_cuda
