@@ -235,6 +235,10 @@ class ModelCheckpoint:
                 "best_model_path": self.best_model_path, "current_score": self.current_score,
                 "dirpath": self.dirpath}
 
+    def load_state(self, state):
+        self.best_model_score, self.best_model_path = state.get("best_model_score"), state.get("best_model_path", "")
+        self.current_score = state.get("current_score")
+
     def better(self, score):
         if self.best_model_score is None:
             return True

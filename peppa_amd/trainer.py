@@ -39,13 +39,15 @@ class SyntheticPigData:
 
 class Trainer:
     def __init__(self, accumulate_grad_batches=1, limit_train_batches=None, max_steps=None, max_time_s=None,
-                 log_every=10, max_epochs=1, limit_val_batches=None, callbacks=(), default_root_dir=None, **ignored):
+                 log_every=10, max_epochs=1, limit_val_batches=None, callbacks=(), default_root_dir=None,
+                 resume_from_checkpoint=None, **ignored):
         self.accumulate = max(1, int(accumulate_grad_batches))
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.max_steps, self.max_time_s, self.log_every = max_steps, max_time_s, log_every
         self.max_epochs, self.callbacks = max_epochs, list(callbacks)
         self.global_step = self.current_epoch = 0
         self.callback_metrics = {}
+        self.resume_from_checkpoint = resume_from_checkpoint      # Lightning 1.4 Trainer argument of the same name
         self.default_root_dir = default_root_dir
         if default_root_dir is not None:      # Lightning: {root}/lightning_logs/version_N/checkpoints
             for cb in self.callbacks:
@@ -82,9 +84,12 @@ class Trainer:
             os.makedirs(self.default_root_dir, exist_ok=True)     # Lightning's logger: hparams.yaml beside checkpoints/
             with open(os.path.join(self.default_root_dir, "hparams.yaml"), "w") as f:
                 yaml.safe_dump(dict(net.config), f)
+        first_epoch = 0
+        if self.resume_from_checkpoint is not None:
+            first_epoch = self._restore(net, optim, self.resume_from_checkpoint)
         t0 = time.time()
         optim.zero_grad(set_to_none=True)
-        for epoch in range(self.max_epochs):
+        for epoch in range(first_epoch, self.max_epochs):
             self.current_epoch = epoch
             if self._train_epoch(net, data, optim, buckets, t0):
                 break
@@ -95,6 +100,22 @@ class Trainer:
                     if rank0:
                         cb.on_validation_end(net, optim, epoch, self.global_step, metrics)
         return net
+
+    def _restore(self, net, optim, path):
+        """Weights, optimizer state (per-parameter step / next_m / next_v), counters and the callbacks' best score
+        from a checkpoint written after an epoch's validation; training continues with the next epoch."""
+        from .checkpoint import callback_states, load_checkpoint
+        cp = load_checkpoint(path)
+        net.load_state_dict(cp["state_dict"])
+        if cp.get("optimizer_states"):
+            optim.load_state_dict(cp["optimizer_states"][0])     # torch moves the state to each parameter's device
+        self.global_step = int(cp.get("global_step", 0))
+        for state in callback_states(cp):
+            for cb in self.callbacks:
+                if getattr(cb, "monitor", None) == state.get("monitor"):
+                    cb.load_state(state)
+        log.info("resumed from %s (epoch %d, step %d)", path, cp.get("epoch", 0), self.global_step)
+        return int(cp.get("epoch", -1)) + 1
 
     def _train_epoch(self, net, data, optim, buckets, t0):
         """True when a step / time limit ended training."""

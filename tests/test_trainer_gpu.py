@@ -56,3 +56,41 @@ def test_fit_validate_checkpoint_reload(tmp_path):
     # saving must not disturb the live optimizer state (it is copied to the host, never moved there)
     for st in trainer.optimizer.state.values():
         assert st["next_m"].is_cuda and st["next_v"].is_cuda
+
+
+@pytest.mark.gpu
+def test_resume_continues_where_the_checkpoint_stopped(tmp_path):
+    """Two epochs in one run == one epoch, checkpoint, resume for the second: same step counters, same optimizer
+    schedule position, and the restored run starts from the stored weights bit for bit."""
+    import pig.models
+    from pig.execution import default_config
+    from peppa_amd.checkpoint import ModelCheckpoint, load_checkpoint
+    from peppa_amd.trainer import SyntheticPigData, Trainer
+    cfg = copy.deepcopy(default_config)
+    cfg["video"]["pretrained"] = cfg["audio"]["pretrained"] = False
+    cfg["video"]["static"], cfg["video"]["version"] = False, "r2plus1d_18"
+    cfg["data"]["train"]["batch_size"] = 26
+    data = SyntheticPigData(cfg["data"], frames=4, size=32, samples=8000, steps_per_epoch=2, val_batches=4)
+    root = str(tmp_path / "run")
+    torch.manual_seed(0)
+    net = pig.models.PeppaPig(cfg).cuda()
+    cb = ModelCheckpoint(monitor="valnarr_triplet", mode="max", save_last=True)
+    Trainer(max_epochs=1, callbacks=[cb], default_root_dir=root).fit(net, data)
+    last = os.path.join(root, "checkpoints", "last.ckpt")
+    stored = load_checkpoint(last)
+    assert stored["epoch"] == 0 and stored["global_step"] == 2
+
+    torch.manual_seed(1)                                  # different init: everything must come from the file
+    net2 = pig.models.PeppaPig(cfg).cuda()
+    cb2 = ModelCheckpoint(monitor="valnarr_triplet", mode="max", save_last=True)
+    trainer = Trainer(max_epochs=2, callbacks=[cb2], default_root_dir=root, resume_from_checkpoint=last)
+    optim = net2.configure_optimizers()
+    assert trainer._restore(net2, optim, last) == 1 and trainer.global_step == 2
+    for k, v in net2.state_dict().items():
+        assert torch.equal(v.cpu(), stored["state_dict"][k]), k
+    for st in optim.state.values():
+        assert st["step"] == 2 and st["next_m"].is_cuda
+    assert float(cb2.best_model_score) == pytest.approx(float(cb.best_model_score))
+    trainer.fit(net2, data)
+    assert trainer.global_step == 4 and trainer.current_epoch == 1
+    assert load_checkpoint(last)["global_step"] == 4
