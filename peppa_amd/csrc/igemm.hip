@@ -18,6 +18,7 @@
 int pp_opt_xcd_remap_igemm = 1;
 int pp_opt_persistent = 1;
 int pp_opt_win_tall = 1;       // window kernel: 512-row tiles (four row tiles per wave) for narrow outputs
+int pp_opt_win_temporal = 1;   // window kernel also for (3,1,1) stride-1 convs (frames-by-positions tiles)
 int pp_opt_win_igemm = 1024;   // window kernel for (1,3,3) stride-1 convs (forward / data gradient) once M >= this (0 = never)
 int pp_opt_sw_wgrad = 4096;    // sliding-window weight gradient for (1,3,3) stride-1 convs once M >= this (0 = never)
 int pp_opt_ring_wgrad = 0;      // LDS-DMA ring weight gradient once the reduce dimension has this many rows (0 = never)
@@ -28,6 +29,7 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "xcd_remap_igemm")) { pp_opt_xcd_remap_igemm = value; return PP_OK; }
   if (!strcmp(name, "win_tall")) { pp_opt_win_tall = value; return PP_OK; }
   if (!strcmp(name, "win_igemm")) { pp_opt_win_igemm = value; return PP_OK; }
+  if (!strcmp(name, "win_temporal")) { pp_opt_win_temporal = value; return PP_OK; }
   if (!strcmp(name, "sw_wgrad")) { pp_opt_sw_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_wgrad")) { pp_opt_ring_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_igemm")) { pp_opt_ring = value; return PP_OK; }

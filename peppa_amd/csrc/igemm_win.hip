@@ -18,6 +18,7 @@
 
 extern int pp_opt_xcd_remap_igemm;
 extern int pp_opt_win_tall;
+extern int pp_opt_win_temporal;
 
 namespace {
 
@@ -36,13 +37,15 @@ __device__ __forceinline__ void lds_dma16(const buffer_rsrc rs, unsigned char* d
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, off, 0, 0, 0);
 }
 
-__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uniform (0..4 here)
+__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uniform (0..6 here)
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -54,6 +57,9 @@ struct WinGeom {
   int cstride;   // A row stride (elements)
   int cg;        // A channels per tap (= K / 9)
   int sign;      // +1 forward, -1 data gradient (source = m - off)
+  // temporal (3,1,1) variant: a tile is ALL T frames of PB = BM / T consecutive positions of one clip
+  FastDiv dBlk;  // position blocks per clip (H*W / PB)
+  int nblk, T, HW, PB, pshift;
 };
 
 struct WinArgs {
@@ -68,7 +74,11 @@ struct WinArgs {
 // MT = 16-row tiles per wave (2: 256-row workgroup tile; 4: 512 rows -- narrow outputs, where a weight fragment would
 // otherwise feed only two MFMAs per load and the per-K-step bookkeeping outweighs the matrix work).
 // NBS = weight ring slots (3: two K-steps in flight; 2, where LDS is short: one).
-template <int WN, int CC, bool RES, int MT, int NBS>
+// TW = temporal: the (3,1,1) stride-1 convolutions.  Their taps are +-H*W rows apart, far more than a halo can hold, so
+// the tile is turned instead: all T frames of PB = BM / T consecutive positions of one clip (window row = frame * PB +
+// position).  Then every tap is the window offset +-PB, frames -1 and T are the masked zero row, no halo is loaded at
+// all and every activation byte is read once (the gather kernel re-read the layer-1 input 2.6 times).
+template <int WN, int CC, bool RES, int MT, int NBS, bool TW>
 __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap) {
   constexpr int BM = 16 * MT * NW;
@@ -81,7 +91,8 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   static_assert(WIN_BYTES % 1024 == 0, "window = whole DMA pieces");
   constexpr int NWP = (WPIECES + NW - 1) / NW;                // window pieces per wave and phase
   constexpr int NBI = (BN * 8 + NT - 1) / NT;                 // weight pieces per wave and K-step (last one maybe absent)
-  constexpr int KC = 9 * CC;                                  // flat K of one channel chunk: (tap, channel)
+  constexpr int NTAP = TW ? 3 : 9;
+  constexpr int KC = NTAP * CC;                               // flat K of one channel chunk: (tap, channel)
   constexpr int NKC = (KC + BK - 1) / BK;                     // K-steps per chunk
   constexpr int PPK = (NWP + NKC - 1) / NKC;                  // window pieces issued per K-step
   static_assert(NBS == 2 || NBS == 3, "weight ring");
@@ -113,8 +124,12 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   const int nchunk = g.cg / CC;
 
   if (tid < 64) ((unsigned*)zrow)[tid] = 0u;
-  if (tid < 9) lut[tid] = g.sign * ((tid / 3 - 1) * g.W + (tid % 3 - 1));
+  if (tid < NTAP) lut[tid] = TW ? g.sign * (tid - 1) * g.PB : g.sign * ((tid / 3 - 1) * g.W + (tid % 3 - 1));
   __syncthreads();
+  auto tw_row = [&](const int tile_m, const int lr) __attribute__((always_inline)) -> int {   // global row of tile row lr
+    const int b = (int)fdiv((uint32_t)tile_m, g.dBlk);
+    return (b * g.T + (lr >> g.pshift)) * g.HW + (tile_m - b * g.nblk) * g.PB + (lr & (g.PB - 1));
+  };
 
   // ---- window DMA: piece q = wave + 8 k lands 1 KiB lane-linear; this lane's (window row, source byte column) -------
   int w_row[NWP];
@@ -135,8 +150,9 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   auto dma_window_piece = [&](const int k, unsigned char* wbuf, const int m0, const int chunk) __attribute__((always_inline)) {
     const int q = wave + NW * k;
     if (q < WPIECES) {
-      const int srow = m0 - HALO + w_row[k];
-      const bool ok = (w_col[k] != OOB) & ((unsigned)srow < (unsigned)g.M);
+      const int lr = w_row[k] - HALO;
+      const int srow = TW ? tw_row(m0 / BM, lr) : m0 + lr;
+      const bool ok = (w_col[k] != OOB) & (TW ? (unsigned)lr < (unsigned)BM : (unsigned)srow < (unsigned)g.M);
       lds_dma16(rsA, wbuf + q * 1024, ok ? (unsigned)(srow * g.cstride + chunk * CC) * 2u + w_col[k] : OOB);
     }
   };
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     jB = 0;
   };
   auto dma_weights = [&](unsigned char* slot) __attribute__((always_inline)) {   // issue the cursor's K-step, advance
-    const bool k_ok = tapB < 9;
+    const bool k_ok = tapB < NTAP;
     const unsigned koff = (unsigned)(tapB * g.cg + chunkB * CC + cB) * 2u;
     unsigned char* dst = slot + (8 * wave) * 128;
 #pragma unroll
@@ -185,6 +201,14 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      if (TW) {
+        const int frame = (wave * (16 * MT) + mt * 16 + fr) >> g.pshift;
+        unsigned v = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) v |= (unsigned)((unsigned)(frame + g.sign * (t - 1)) < (unsigned)g.T) << t;
+        vmask[mt] = v;                     // (M is a whole number of tiles)
+        continue;
+      }
       const int m = mb * BM + wave * (16 * MT) + mt * 16 + fr;
       const uint32_t q1 = fdiv((uint32_t)m, g.dW_);
       const int w = m - (int)q1 * g.W;
@@ -214,13 +238,13 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int tap = tapA[ks], c = cA[ks];
-      const int roff = lut[tap < 9 ? tap : 0];
+      const int roff = lut[tap < NTAP ? tap : 0];
       bf16x8 af[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int wrow = wave * (16 * MT) + mt * 16 + fr + HALO + roff;
         const int col = CC == 64 ? (((c >> 3) ^ swz(wrow)) << 4) : c * 2;
-        const bool ok = ((vmask[mt] >> tap) & 1u) != 0u;    // (tap >= 9, the K tail, has no bit set)
+        const bool ok = ((vmask[mt] >> tap) & 1u) != 0u;    // (tap >= NTAP, the K tail, has no bit set)
         const unsigned char* a = ok ? win + wrow * XS + col : zrow + fr * 16;
         af[mt] = *(const bf16x8*)a;
       }
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         const int cid = lane + 64 * it;
         const int row = cid / (2 * WN);
         const int ch = cid % (2 * WN);
-        const int m = m_wave + mt * 16 + row;
+        const int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + row) : m_wave + mt * 16 + row;
         const int col = nb_e * BN + ch * 8;
         if (cid < 32 * WN && m < g.M && col < ncols_store) {
           u32x4 vv;   // (inline asm: a plain LDS load here makes hipcc drain the DMAs in flight, see igemm.hip)
@@ -402,7 +426,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   }
 }
 
-template <int WN, int CC, int MT, int NBS>
+template <int WN, int CC, int MT, int NBS, bool TW = false>
 int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   constexpr int BN = 16 * WN, BM = 16 * MT * NW;
   const pp_gather& gg = d.g;
@@ -411,6 +435,11 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   g.sign = gg.mode == PP_CONV_FWD ? 1 : -1;
   g.dW_ = make_fastdiv((uint32_t)gg.Gw);
   g.dH_ = make_fastdiv((uint32_t)gg.Gh);
+  g.T = gg.Gt; g.HW = gg.Gh * gg.Gw; g.PB = TW ? BM / gg.Gt : 1;
+  g.pshift = 0;
+  while ((1 << g.pshift) < g.PB) ++g.pshift;
+  g.nblk = g.HW / g.PB;
+  g.dBlk = make_fastdiv((uint32_t)(g.nblk > 0 ? g.nblk : 1));
   WinArgs a;
   a.A = (const bfraw*)d.A; a.Bt = (const bfraw*)d.Bt; a.C = (bfraw*)d.C; a.residual = (const bfraw*)d.residual;
   a.colstats = d.colstats;
@@ -421,8 +450,8 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < 256 ? ntiles : 256;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
-  if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
-  else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+  if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+  else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -434,6 +463,20 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
 int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
   const pp_gather& g = d.g;
   const bool conv = g.mode == PP_CONV_FWD || g.mode == PP_CONV_DGRAD;
+  // temporal (3,1,1) stride-1 convs with 4, 8 or 16 frames: 256-row tiles = all frames of 64 / 32 / 16 positions
+  const int pb = (g.Gt == 4 || g.Gt == 8 || g.Gt == 16) ? 256 / g.Gt : 0;
+  const bool tw_ok = pp_opt_win_temporal && conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE &&
+                     !d.Cpre && !d.omap && g.kt == 3 && g.kh == 1 && g.kw == 1 && g.st == 1 && g.sh == 1 && g.sw == 1 &&
+                     g.pt == 1 && g.ph == 0 && g.pw == 0 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && pb > 0 &&
+                     (g.Gh * g.Gw) % pb == 0 && d.K == 3 * g.cg && d.M % 256 == 0 &&
+                     (long long)d.M * g.cstride < 0x7fffffffLL && (!d.residual || d.ldr % 8 == 0);
+  if (tw_ok) {
+    const int n16 = (d.N + 15) / 16;
+    if (g.cg % 64 == 0 && n16 <= 4) return launch_win<4, 64, 2, 3, true>(d, s);
+    if (g.cg % 64 == 0 && n16 <= 9) return launch_win<9, 64, 2, 3, true>(d, s);
+    if (g.cg % 48 == 0 && g.cg % 64 != 0 && n16 <= 4) return launch_win<4, 48, 2, 3, true>(d, s);
+    return 1;
+  }
   const bool shape_ok = conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre && !d.omap &&
                         g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 &&
                         g.ph == 1 && g.pw == 1 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && g.Gw + 1 <= HALO &&

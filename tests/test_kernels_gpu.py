@@ -748,6 +748,55 @@ def test_window_igemm_matches_gather_igemm(case):
 
 
 @pytest.mark.parametrize("case", [
+    # Ci, Co, B, T, H, W  -- (3,1,1) stride-1 pad-(1,0,0) convs with 4 / 8 / 16 frames: tiles = all frames x positions
+    (144, 64, 2, 16, 8, 8),       # layer-1 temporal: fwd from three 48-channel chunks, dgrad 64 -> 144 columns
+    (45, 64, 3, 16, 4, 12),       # stem: 45 (48) input channels; dgrad to 45 of 48 columns; three clips
+    (144, 64, 1, 8, 8, 12),       # 8 frames: 32 positions per tile
+    (64, 64, 2, 4, 8, 8),         # 4 frames: 64 positions per tile; 64-channel chunks both ways
+    (144, 64, 1, 16, 56, 56),     # layer-1 frame size (196 tiles per clip)
+])
+def test_temporal_window_igemm_matches_gather_igemm(case):
+    """Window kernel in its temporal form (tile = every frame of a block of positions, taps = +-block rows, frames -1
+    and T masked to the zero row) against the gather kernel: forward with BatchNorm statistics, data gradient with
+    and without the fused residual add, and both against torch."""
+    Ci, Co, B, T, Hh, W = case
+    k, s, p = (3, 1, 1), (1, 1, 1), (1, 0, 0)
+    g = torch.Generator().manual_seed(5 * Ci + Co + T)
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    xf = torch.randn(B, Ci, T, Hh, W, generator=g)
+    dyf = torch.randn(B, Co, T, Hh, W, generator=g)
+    x = to_cl(xf, geom.in_cstride)
+    dy = to_cl(dyf, geom.out_cstride)
+    res = torch.randn(geom.Min, geom.in_cstride, generator=g).to(torch.bfloat16).to(DEV)
+    w = torch.randn(Co, Ci, *k, generator=g) / math.sqrt(Ci * 3)
+    wf, wd = L.prep_conv_weights(w.to(DEV), geom)
+    outs = []
+    try:
+        for win in (0, 1):
+            H.set_option("win_temporal", win)
+            y, st = L.conv_fwd(x, geom, wf, stats=True)
+            dx = L.conv_dgrad(dy, geom, wd)
+            dxr = L.conv_dgrad(dy, geom, wd, residual=res)
+            torch.cuda.synchronize()
+            outs.append((y.float(), st.sum(dim=0), dx.float(), dxr.float()))      # (partials cover different row sets)
+    finally:
+        H.set_option("win_temporal", 1)
+    for a, b, name in zip(outs[0], outs[1], ("fwd", "colstats", "dgrad", "dgrad + residual")):
+        assert a.shape == b.shape, name
+        scale = a.abs().max().item()
+        err = (a - b).abs().max().item()
+        tol = (2e-4 if name == "colstats" else 2.0 ** -7) * scale
+        assert err <= tol, f"{name}: temporal window kernel differs by {err} (scale {scale})"
+        assert (a - b).abs().mean().item() <= 1e-3 * scale, name
+    xr = xf.to(torch.bfloat16).float().requires_grad_()
+    wr = w.to(torch.bfloat16).float()
+    yr = F.conv3d(xr, wr, stride=s, padding=p)
+    yr.backward(dyf.to(torch.bfloat16).float())
+    close(from_cl(outs[1][0].to(torch.bfloat16), B, (T, Hh, W), Co), yr.detach(), name="temporal window fwd vs torch")
+    close(from_cl(outs[1][2].to(torch.bfloat16), B, (T, Hh, W), Ci), xr.grad, name="temporal window dgrad vs torch")
+
+
+@pytest.mark.parametrize("case", [
     # Ci, Co, B, T, H, W  -- (3,1,1) stride-1 pad-(1,0,0) convs, the shapes pp_wgrad's temporal window kernel takes
     (144, 64, 2, 5, 8, 8),        # one 144-channel block, 64 rows of dW; frames of exactly 64 positions
     (288, 128, 1, 4, 9, 10),      # two channel blocks, ragged 64-position blocks (90 positions per frame)
