@@ -37,7 +37,7 @@ __device__ __forceinline__ void lds_dma16(const buffer_rsrc rs, unsigned char* d
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, off, 0, 0, 0);
 }
 
-__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uniform (0..6 here)
+__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uniform (0..8 here)
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -46,6 +46,8 @@ __device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uni
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -78,37 +80,55 @@ struct WinArgs {
 // the tile is turned instead: all T frames of PB = BM / T consecutive positions of one clip (window row = frame * PB +
 // position).  Then every tap is the window offset +-PB, frames -1 and T are the masked zero row, no halo is loaded at
 // all and every activation byte is read once (the gather kernel re-read the layer-1 input 2.6 times).
+// The temporal form keeps ALL weight K-steps of a tile resident in the ring (NBS >= K-steps per tile, loaded once per
+// workgroup): its K-steps are short (16 MFMAs per wave with 64 output columns), and re-streaming 8 KB of weights per step
+// from L2 two steps ahead left every step waiting for that DMA.  With resident weights there is no DMA and no barrier
+// inside a phase: one barrier per window.
 template <int WN, int CC, bool RES, int MT, int NBS, bool TW>
 __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap) {
   constexpr int BM = 16 * MT * NW;
-  constexpr int WROWS = BM + 2 * HALO;
+  // temporal tiles with narrow outputs: no halo rows at all and THREE window buffers -- the window of the phase after
+  // next is in flight too, because a phase (3 short K-steps) is far shorter than an HBM round trip
+  constexpr int HALO_ = (TW && WN <= 4) ? 0 : HALO;
+  constexpr int NWIN = (TW && WN <= 4) ? 3 : 2;
+  constexpr int D = NWIN - 1;                                 // phases of window look-ahead
+  constexpr int WROWS = BM + 2 * HALO_;
   constexpr int BN = 16 * WN;
   constexpr int B_BYTES = BN * 128;
   constexpr int XS = CC == 64 ? 128 : CC * 2 + 16;            // window row stride; 128-byte rows are XOR-swizzled
   constexpr int WIN_BYTES = WROWS * XS;
   constexpr int WPIECES = WIN_BYTES / 1024;
   static_assert(WIN_BYTES % 1024 == 0, "window = whole DMA pieces");
-  constexpr int NWP = (WPIECES + NW - 1) / NW;                // window pieces per wave and phase
-  constexpr int NBI = (BN * 8 + NT - 1) / NT;                 // weight pieces per wave and K-step (last one maybe absent)
+  // Wave roles for the LDS-DMA: vmcnt retires in order, so a wave that has a long-latency window piece (HBM) in flight
+  // cannot tell that the weight slice it issued afterwards (L2) has landed.  Waves 0..3 therefore issue only weights
+  // and wait for them step by step; waves 4..7 issue only window pieces -- the WHOLE next window at the start of a
+  // phase -- and wait for them once per phase, so a full window (40-70 KB per CU) is in flight under the phase's
+  // matrix work instead of the one or two pieces a per-step wait allows.  All eight waves multiply.
+  constexpr int NWW = NW / 2;                                 // waves per role
+  constexpr int NWP = (WPIECES + NWW - 1) / NWW;              // window pieces per window wave and phase
+  constexpr int NBI = (BN + 8 * NWW - 1) / (8 * NWW);         // weight pieces per weight wave and K-step (last one maybe absent)
   constexpr int NTAP = TW ? 3 : 9;
   constexpr int KC = NTAP * CC;                               // flat K of one channel chunk: (tap, channel)
   constexpr int NKC = (KC + BK - 1) / BK;                     // K-steps per chunk
-  constexpr int PPK = (NWP + NKC - 1) / NKC;                  // window pieces issued per K-step
-  static_assert(NBS == 2 || NBS == 3, "weight ring");
+  constexpr bool RW = TW;                                     // resident weights
+  static_assert(NBS == 2 || NBS == 3 || (RW && NBS <= 9), "weight ring");
   constexpr int STG_STRIDE = BN * 2 + 16;
   constexpr int STG_BYTES = NW * 16 * STG_STRIDE;
   constexpr int STAT_BYTES = NW * BN * 2 * 4;
   static_assert(STG_BYTES <= WIN_BYTES && STAT_BYTES <= B_BYTES, "the epilogue stages in a window buffer / weight slot");
-  constexpr int SMEM = 2 * WIN_BYTES + NBS * B_BYTES + 256 + 64;
+  static_assert(!RW || WN > 4 || STG_BYTES + STAT_BYTES <= WIN_BYTES, "resident weights: the statistics stage behind the output");
+  constexpr int SMEM = NWIN * WIN_BYTES + NBS * B_BYTES + 256 + 64;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];   // one LDS object (see igemm.hip)
-  unsigned char* const bring = smem + 2 * WIN_BYTES;
-  unsigned char* const zrow = smem + 2 * WIN_BYTES + NBS * B_BYTES;    // 256 zero bytes
+  unsigned char* const bring = smem + NWIN * WIN_BYTES;
+  unsigned char* const zrow = smem + NWIN * WIN_BYTES + NBS * B_BYTES;    // 256 zero bytes
   int* const lut = (int*)(zrow + 256);                                 // row offset of each tap
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool win_wave = wave >= NWW;                          // role (wave-uniform)
+  const int rwave = win_wave ? wave - NWW : wave;             // index inside the role
   const int fr = lane & 15, fq = lane >> 4;
   const int G = gridDim.x, bid = blockIdx.x;
   auto tile_index = [&](int it) __attribute__((always_inline)) -> int {   // persistent walk, XCD-contiguous (igemm.hip)
@@ -131,12 +151,12 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     return (b * g.T + (lr >> g.pshift)) * g.HW + (tile_m - b * g.nblk) * g.PB + (lr & (g.PB - 1));
   };
 
-  // ---- window DMA: piece q = wave + 8 k lands 1 KiB lane-linear; this lane's (window row, source byte column) -------
+  // ---- window DMA: piece q = rwave + 4 k lands 1 KiB lane-linear; this lane's (window row, source byte column) ------
   int w_row[NWP];
   unsigned w_col[NWP];
 #pragma unroll
   for (int k = 0; k < NWP; ++k) {
-    const int q = wave + NW * k;
+    const int q = rwave + NWW * k;
     if (CC == 64) {
       w_row[k] = q * 8 + (lane >> 3);
       w_col[k] = (unsigned)(((lane & 7) ^ swz(w_row[k])) * 16);   // slot (lane & 7) holds chunk slot ^ swz(row)
@@ -148,17 +168,18 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     }
   }
   auto dma_window_piece = [&](const int k, unsigned char* wbuf, const int m0, const int chunk) __attribute__((always_inline)) {
-    const int q = wave + NW * k;
+    const int q = rwave + NWW * k;
     if (q < WPIECES) {
-      const int lr = w_row[k] - HALO;
+      const int lr = w_row[k] - HALO_;
       const int srow = TW ? tw_row(m0 / BM, lr) : m0 + lr;
       const bool ok = (w_col[k] != OOB) & (TW ? (unsigned)lr < (unsigned)BM : (unsigned)srow < (unsigned)g.M);
       lds_dma16(rsA, wbuf + q * 1024, ok ? (unsigned)(srow * g.cstride + chunk * CC) * 2u + w_col[k] : OOB);
     }
   };
-  // ---- weight DMA: as igemm.hip's ring (rows (tid >> 3) + 64 i, slot tid & 7 holds K chunk (tid & 7) ^ swz(row)) ------
-  const int kqB = (tid & 7) ^ swz(tid >> 3);
-  const bool b_last = 8 * wave + 64 * (NBI - 1) < BN;   // does this wave own a piece in the last weight pass
+  // ---- weight DMA (waves 0..3): rows 8 wave + (lane >> 3) + 32 i, slot lane & 7 holds K chunk (lane & 7) ^ swz(row) ------
+  const int brow0 = 8 * rwave + (lane >> 3);
+  const int kqB = (lane & 7) ^ swz(brow0);
+  const bool b_last = 8 * rwave + 8 * NWW * (NBI - 1) < BN;   // does this wave own a piece in the last weight pass
   const int nB = b_last ? NBI : NBI - 1;
   unsigned bbase[NBI];
   int tapB = 0, cB = 0, chunkB = 0, jB = 0;             // cursor of the next weight K-step to issue (inside the tile)
@@ -172,10 +193,10 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   auto dma_weights = [&](unsigned char* slot) __attribute__((always_inline)) {   // issue the cursor's K-step, advance
     const bool k_ok = tapB < NTAP;
     const unsigned koff = (unsigned)(tapB * g.cg + chunkB * CC + cB) * 2u;
-    unsigned char* dst = slot + (8 * wave) * 128;
+    unsigned char* dst = slot + (8 * rwave) * 128;
 #pragma unroll
     for (int i = 0; i < NBI; ++i)
-      if (i < NBI - 1 || b_last) lds_dma16(rsB, dst + 64 * i * 128, (k_ok & (bbase[i] != OOB)) ? bbase[i] + koff : OOB);
+      if (i < NBI - 1 || b_last) lds_dma16(rsB, dst + 8 * NWW * i * 128, (k_ok & (bbase[i] != OOB)) ? bbase[i] + koff : OOB);
     cB += BK;
     while (cB >= CC) { cB -= CC; ++tapB; }
     if (++jB == NKC) {
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     mb = tile / nblk_n;
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
-      const int brow = (tid >> 3) + 64 * i;
+      const int brow = brow0 + 8 * NWW * i;
       const int n = nb * BN + brow;
       bbase[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : OOB;
     }
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       bf16x8 af[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int wrow = wave * (16 * MT) + mt * 16 + fr + HALO + roff;
+        const int wrow = wave * (16 * MT) + mt * 16 + fr + HALO_ + roff;
         const int col = CC == 64 ? (((c >> 3) ^ swz(wrow)) << 4) : c * 2;
         const bool ok = ((vmask[mt] >> tap) & 1u) != 0u;    // (tap >= NTAP, the K tail, has no bit set)
         const unsigned char* a = ok ? win + wrow * XS + col : zrow + fr * 16;
@@ -353,12 +374,31 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   int wsel = 0;                       // window buffer of the current phase
   int bsl = 0;                        // weight ring slot of the current K-step
   const int S = nchunk * NKC;         // K-steps per tile
-#pragma unroll
-  for (int k = 0; k < NWP; ++k) dma_window_piece(k, smem, mb * BM, 0);
   reset_b_cursor();
-  dma_weights(bring);
-  if (NBS == 3 && S > 1) dma_weights(bring + B_BYTES);
-  int last_batch = 0;                 // DMA instructions this wave issued in the previous iteration
+  int my_np = 0;                      // window pieces this wave issues per window
+#pragma unroll
+  for (int k = 0; k < NWP; ++k) my_np += (rwave + NWW * k < WPIECES) ? 1 : 0;
+  // (tile iteration, chunk) of the phase `ahead` phases after (it_, chunk_); tile < 0: past the last phase
+  auto issue_window = [&](const int it_, const int chunk_, const int ahead, const int cur_tile, unsigned char* buf) __attribute__((always_inline)) -> int {
+    int pc = chunk_ + ahead, pit = it_;
+    while (pc >= nchunk) { pc -= nchunk; ++pit; }
+    const int ptile = pit == it_ ? cur_tile : tile_index(pit);
+    if (ptile < 0) return 0;
+#pragma unroll
+    for (int k = 0; k < NWP; ++k) dma_window_piece(k, buf, (ptile / nblk_n) * BM, pc);
+    return my_np;
+  };
+  int last_win = 0;                   // window pieces this (window) wave issued at the previous phase start
+  if (win_wave) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) last_win = issue_window(0, 0, a, tile, smem + a * WIN_BYTES);
+  } else if (RW) {
+    for (int i = 0; i < S; ++i) dma_weights(bring + i * B_BYTES);   // (the launcher checked S <= NBS; same N block for every tile)
+  } else {
+    dma_weights(bring);
+    if (NBS == 3 && S > 1) dma_weights(bring + B_BYTES);
+  }
+  int last_batch = 0;                 // weight DMAs this (weight) wave issued in the previous iteration
   bool drain = true;                  // first step of a tile: wait for everything (epilogue stores included)
   auto next_slot = [&](int sl) __attribute__((always_inline)) { return sl + 1 == NBS ? 0 : sl + 1; };
   while (true) {
@@ -367,47 +407,43 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
 #pragma unroll
       for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int next_tile = tile_index(it + 1);
-    const int next_m0 = next_tile >= 0 ? (next_tile / nblk_n) * BM : 0;
     int s = 0;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
       reset_a_cursor();
-      // the phase after this one: next chunk of this tile, or chunk 0 of the next tile, or nothing
-      const bool more_chunks = chunk + 1 < nchunk;
-      const bool have_next = more_chunks || next_tile >= 0;
-      const int nm0 = more_chunks ? mb * BM : next_m0;
-      const int nchunk_i = more_chunks ? chunk + 1 : 0;
       unsigned char* const win = smem + wsel * WIN_BYTES;
-      unsigned char* const nwin = smem + (wsel ^ 1) * WIN_BYTES;
+      unsigned char* const nwin = smem + (wsel + D >= NWIN ? wsel + D - NWIN : wsel + D) * WIN_BYTES;   // of the phase D ahead
       for (int j = 0; j < NKC; ++j, ++s) {
-        // three slots: everything but the batch of the previous iteration (the weights of step s + 1) must have landed;
-        // two slots: that batch IS the weights of this step
-        wait_vmcnt_dyn((drain || NBS == 2) ? 0 : last_batch);
+        // weight waves, three slots: everything but the batch of the previous iteration (the weights of step s + 1) must
+        // have landed; two slots: that batch IS the weights of this step.  Window waves: this phase's window, issued at
+        // the start of the previous phase, must have landed when the phase starts; nothing to wait for inside a phase.
+        if (win_wave) {
+          // this phase's window has landed once only the younger one (D = 2) is still in flight; a tile's first phase
+          // also waits for the epilogue's stores, which sit between them in the counter
+          if (j == 0) wait_vmcnt_dyn((drain || D == 1) ? 0 : last_win);
+        } else {
+          wait_vmcnt_dyn((drain || NBS == 2 || RW) ? 0 : last_batch);
+        }
         drain = false;
-        __builtin_amdgcn_s_barrier();
-        int batch = 0;
-        if (s + (NBS - 1) < S) {
-          dma_weights(bring + (NBS == 3 ? (bsl >= 1 ? bsl - 1 : 2) : (bsl ^ 1)) * B_BYTES);
-          batch += nB;
-        }
-        if (have_next) {
-#pragma unroll
-          for (int q = 0; q < PPK; ++q) {
-            const int k = j * PPK + q;
-            if (k < NWP) {
-              dma_window_piece(k, nwin, nm0, nchunk_i);
-              batch += (wave + NW * k < WPIECES) ? 1 : 0;
-            }
+        if (!RW || j == 0) __builtin_amdgcn_s_barrier();
+        if (win_wave) {
+          if (j == 0) last_win = issue_window(it, chunk, D, tile, nwin);
+        } else if (!RW) {
+          int batch = 0;
+          if (s + (NBS - 1) < S) {
+            dma_weights(bring + (NBS == 3 ? (bsl >= 1 ? bsl - 1 : 2) : (bsl ^ 1)) * B_BYTES);
+            batch += nB;
           }
+          last_batch = batch;
         }
-        last_batch = batch;
-        compute(win, bring + bsl * B_BYTES);
+        compute(win, bring + (RW ? s : bsl) * B_BYTES);
         bsl = next_slot(bsl);
       }
-      wsel ^= 1;
+      wsel = wsel + 1 == NWIN ? 0 : wsel + 1;
     }
     const int mb_done = mb, nb_done = nb;
-    unsigned char* const ebuf = smem + (wsel ^ 1) * WIN_BYTES;   // the window just consumed stages the output
-    unsigned char* const sbuf = bring + (bsl == 0 ? NBS - 1 : bsl - 1) * B_BYTES;   // ... the weight slot just consumed the statistics
+    unsigned char* const ebuf = smem + (wsel == 0 ? NWIN - 1 : wsel - 1) * WIN_BYTES;   // the window just consumed stages the output
+    unsigned char* const sbuf = RW ? ebuf + STG_BYTES                                // ... the weight slot just consumed the statistics
+                                   : bring + (bsl == 0 ? NBS - 1 : bsl - 1) * B_BYTES;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                               // every wave is done reading it
     if (next_tile >= 0) {                                       // the next tile's first weight steps fly under the epilogue
@@ -415,8 +451,10 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       reset_b_cursor();
       // (two slots: the slot just consumed holds the statistics during the epilogue, so only the other one is refilled:
       // it is the slot of step 0 of the next tile because bsl already points past the consumed one)
-      dma_weights(bring + bsl * B_BYTES);
-      if (NBS == 3 && S > 1) dma_weights(bring + next_slot(bsl) * B_BYTES);
+      if (!win_wave && !RW) {
+        dma_weights(bring + bsl * B_BYTES);
+        if (NBS == 3 && S > 1) dma_weights(bring + next_slot(bsl) * B_BYTES);
+      }
     }
     epilogue(mb_done, nb_done, ebuf, sbuf);
     if (next_tile < 0) break;
@@ -471,10 +509,12 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
                      (g.Gh * g.Gw) % pb == 0 && d.K == 3 * g.cg && d.M % 256 == 0 &&
                      (long long)d.M * g.cstride < 0x7fffffffLL && (!d.residual || d.ldr % 8 == 0);
   if (tw_ok) {
+    // resident weights: every K-step of a tile has its own ring slot (3 per channel chunk), one column block
     const int n16 = (d.N + 15) / 16;
-    if (g.cg % 64 == 0 && n16 <= 4) return launch_win<4, 64, 2, 3, true>(d, s);
-    if (g.cg % 64 == 0 && n16 <= 9) return launch_win<9, 64, 2, 3, true>(d, s);
-    if (g.cg % 48 == 0 && g.cg % 64 != 0 && n16 <= 4) return launch_win<4, 48, 2, 3, true>(d, s);
+    if (g.cg == 64 && n16 <= 4) return launch_win<4, 64, 2, 3, true>(d, s);
+    if (g.cg == 64 && n16 <= 9 && !d.colstats) return launch_win<9, 64, 2, 3, true>(d, s);
+    if (g.cg == 48 && n16 <= 4) return launch_win<4, 48, 2, 3, true>(d, s);
+    if (g.cg == 144 && n16 <= 4) return launch_win<4, 48, 2, 9, true>(d, s);
     return 1;
   }
   const bool shape_ok = conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre && !d.omap &&
