@@ -256,29 +256,35 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     }
   };
   auto compute = [&](const unsigned char* win, const unsigned char* bslot) __attribute__((always_inline)) {
+    // every fragment of the K-step is requested before the first MFMA: written as "load one weight fragment, use it"
+    // hipcc keeps ONE fragment register and waits lgkmcnt(0) before every MFMA pair, i.e. one exposed LDS round trip
+    // (~100 cycles) per 32 cycles of matrix work
+    bf16x8 af[2][MT], bfm[2][WN];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int tap = tapA[ks], c = cA[ks];
       const int roff = lut[tap < NTAP ? tap : 0];
-      bf16x8 af[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int wrow = wave * (16 * MT) + mt * 16 + fr + HALO_ + roff;
         const int col = CC == 64 ? (((c >> 3) ^ swz(wrow)) << 4) : c * 2;
         const bool ok = ((vmask[mt] >> tap) & 1u) != 0u;    // (tap >= NTAP, the K tail, has no bit set)
         const unsigned char* a = ok ? win + wrow * XS + col : zrow + fr * 16;
-        af[mt] = *(const bf16x8*)a;
+        af[ks][mt] = *(const bf16x8*)a;
       }
       const int fsw = ((ks * 4 + fq) ^ swz(fr)) << 4;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const bf16x8 bfm = *(const bf16x8*)(bslot + (j * 16 + fr) * 128 + fsw);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfm, acc[mt][j], 0, 0, 0);
-      }
+      for (int j = 0; j < WN; ++j) bfm[ks][j] = *(const bf16x8*)(bslot + (j * 16 + fr) * 128 + fsw);
       cA[ks] += BK;
       while (cA[ks] >= CC) { cA[ks] -= CC; ++tapA[ks]; }
     }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][mt], bfm[ks][j], acc[mt][j], 0, 0, 0);
   };
 
   // ---- epilogue (plain bf16 store, optional residual add, optional BatchNorm column statistics); igemm.hip's ------
