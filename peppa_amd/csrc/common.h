@@ -64,6 +64,16 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // ---- wave / block reductions ----------------------------------------------------------
+// sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane, added in the order
+// (r0 + r1) + (r2 + r3) like `v += shfl_xor(v, 16); v += shfl_xor(v, 32)`.  gfx950's v_permlane16_swap / 32_swap do it
+// on the VALU; __shfl_xor goes through ds_bpermute (an LDS round trip per step).
+__device__ __forceinline__ float sum_rows4(float v) {
+  unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // {r0,r0,r2,r2}, {r1,r1,r3,r3}
+  u = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lo,lo}, {hi,hi}
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

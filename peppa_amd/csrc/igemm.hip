@@ -455,10 +455,8 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
           s1 += v;
           s2 += v * v;
         }
-      s1 += __shfl_xor(s1, 16);
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 16);
-      s2 += __shfl_xor(s2, 32);
+      s1 = sum_rows4(s1);
+      s2 = sum_rows4(s2);
       if (fq == 0) {
         statbuf[(wave * BN + j * 16 + fr) * 2 + 0] = s1;
         statbuf[(wave * BN + j * 16 + fr) * 2 + 1] = s2;
