@@ -74,15 +74,29 @@ __device__ __forceinline__ float sum_rows4(float v) {
   const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lo,lo}, {hi,hi}
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// full-wave reductions on the VALU: DPP inside a 16-lane row (quad swaps, half-row mirror, row mirror), then the two
+// permlane swaps across rows; every lane gets the result.  (__shfl_xor = ds_bpermute: six LDS round trips.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f<0xB1>(v);     // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_f<0x4E>(v);     // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_f<0x141>(v);    // row_half_mirror: the other quad of the 8-lane half row
+  v += dpp_f<0x140>(v);    // row_mirror: the other half of the 16-lane row
+  return sum_rows4(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+  const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 // sum over a block of NW waves; `red` needs NW floats of LDS; result valid in all threads
 template <int NW>
