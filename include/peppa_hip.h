@@ -28,6 +28,7 @@ int pp_version(void);
  *   "persistent_igemm"                    0/1   persistent workgroups with cross-tile prefetch (plain epilogues)
  *   "ring_igemm"   n   LDS-DMA ring GEMM once there are >= n 256-row tiles (0 = never; default 128)
  *   "win_igemm"    n   window kernel for (1,3,3) stride-1 convs, forward / data gradient, once M >= n (default 1024)
+ *   "win_temporal" 0/1 the same kernel in its temporal form for (3,1,1) stride-1 convs with 4 / 8 / 16 frames (default 1)
  *   "sw_wgrad"     n   sliding-window weight gradients ((1,3,3) and (3,1,1) stride-1 convs) once M >= n (default 4096;
  *                      1 also takes shapes the (3,1,1) kernel would decline as not worth it)
  *   "ring_wgrad"   n   LDS-DMA ring variant of the generic weight gradient once M >= n (default 0 = never) */
