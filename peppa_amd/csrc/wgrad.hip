@@ -720,7 +720,10 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
     if (w9) return v6 ? launch_ring<9, 6>(d, s) : launch_ring<9, 8>(d, s);
     return v6 ? launch_ring<8, 6>(d, s) : launch_ring<8, 8>(d, s);
   }
-  switch (pick_wi(n16)) {
+  // dense operands (the transformer GEMMs, M = a few thousand rows): the 240-row tile runs one workgroup per CU and its
+  // grid (tiles x M-splits ~ 400) then needs two rounds; 128-row tiles fit 512 workgroups in one (ffn1: 144 -> 80 us)
+  const int wi = (d.g.mode == PP_DENSE && pick_wi(n16) == 15 && n16 % 8 == 0) ? 8 : pick_wi(n16);
+  switch (wi) {
     case 15: return launch_wi<15>(d, s);
     case 9: return launch_wi<9>(d, s);
     case 8: return launch_wi<8>(d, s);

@@ -59,7 +59,7 @@ def dense_case(name, M, N, K):
     if not only or "dgrad" in only:
         t = timeit(lambda: L.linear_dgrad(dy, M, wt, K)); res.append(f"dgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF")
     if not only or "wgrad" in only:
-        t = timeit(lambda: L.linear_wgrad(x, dy, M, N, K)); res.append(f"wgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF")
+        t = timeit(lambda: L.linear_wgrad(x, dy, M, N, K, want_bias=not os.environ.get('NO_BIAS'))); res.append(f"wgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF")
     print(f"{name:28s} M={M:8d} " + " | ".join(res), flush=True)
 
 
