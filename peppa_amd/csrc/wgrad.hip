@@ -600,7 +600,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad_ring_kernel(const pp_wgrad_
 
 int pick_wi(int n16) {
   static const int cand[] = {15, 9, 8, 4, 3, 2};
-  static const float eff[] = {1.0f, 0.96f, 0.97f, 0.8f, 0.7f, 0.55f};  // ties between 9 and 8 go to 8 (fewer registers)
+  // measured efficiency per row-tile count.  The 240-row tile (15) runs ONE workgroup per CU (120 accumulator registers)
+  // and loses the latency hiding of a second one: on the shapes that used to pick it, 128-row tiles are 1.4-1.8x faster
+  // (layer-2.0 strided conv, Ni = 230: 777 -> 538 us; ffn1, Ni = 3072: 143 -> 78 us), so it only wins by a wide margin.
+  static const float eff[] = {0.72f, 0.96f, 0.97f, 0.8f, 0.7f, 0.55f};  // ties between 9 and 8 go to 8 (fewer registers)
   int best = 2;
   float best_cost = 1e30f;
   for (int i = 0; i < 6; ++i) {
@@ -720,10 +723,7 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
     if (w9) return v6 ? launch_ring<9, 6>(d, s) : launch_ring<9, 8>(d, s);
     return v6 ? launch_ring<8, 6>(d, s) : launch_ring<8, 8>(d, s);
   }
-  // dense operands (the transformer GEMMs, M = a few thousand rows): the 240-row tile runs one workgroup per CU and its
-  // grid (tiles x M-splits ~ 400) then needs two rounds; 128-row tiles fit 512 workgroups in one (ffn1: 144 -> 80 us)
-  const int wi = (d.g.mode == PP_DENSE && pick_wi(n16) == 15 && n16 % 8 == 0) ? 8 : pick_wi(n16);
-  switch (wi) {
+  switch (pick_wi(n16)) {
     case 15: return launch_wi<15>(d, s);
     case 9: return launch_wi<9>(d, s);
     case 8: return launch_wi<8>(d, s);
