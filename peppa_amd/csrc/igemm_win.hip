@@ -379,23 +379,32 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   int bsl = 0;                        // weight ring slot of the current K-step
   const int S = nchunk * NKC;         // K-steps per tile
   reset_b_cursor();
-  int my_np = 0;                      // window pieces this wave issues per window
-#pragma unroll
-  for (int k = 0; k < NWP; ++k) my_np += (rwave + NWW * k < WPIECES) ? 1 : 0;
   // (tile iteration, chunk) of the phase `ahead` phases after (it_, chunk_); tile < 0: past the last phase
-  auto issue_window = [&](const int it_, const int chunk_, const int ahead, const int cur_tile, unsigned char* buf) __attribute__((always_inline)) -> int {
+  // k0 .. k0 + nk - 1: the pieces to issue now.  The temporal form issues a whole window at the start of a phase (its
+  // phases are three short K-steps); the spatial forms spread it over the K-steps of the phase.
+  // (PMC note: the 512-row 48-channel-chunk variant fetches 1.55 GB for the 0.93-GB layer-1 data-gradient input, the
+  // 256-row one 0.95 GB: consecutive chunks share 128-byte lines of the 288-byte rows, and 32 CUs x 2 x 70 KB of windows
+  // in flight no longer fit one XCD's 4-MB L2.  It is still the faster of the two, 775 vs 945 us.)
+  auto issue_window = [&](const int it_, const int chunk_, const int ahead, const int cur_tile, unsigned char* buf,
+                          const int k0, const int nk) __attribute__((always_inline)) -> int {
     int pc = chunk_ + ahead, pit = it_;
     while (pc >= nchunk) { pc -= nchunk; ++pit; }
     const int ptile = pit == it_ ? cur_tile : tile_index(pit);
     if (ptile < 0) return 0;
+    int n = 0;
 #pragma unroll
-    for (int k = 0; k < NWP; ++k) dma_window_piece(k, buf, (ptile / nblk_n) * BM, pc);
-    return my_np;
+    for (int k = 0; k < NWP; ++k)
+      if (k >= k0 && k < k0 + nk) {
+        dma_window_piece(k, buf, (ptile / nblk_n) * BM, pc);
+        n += (rwave + NWW * k < WPIECES) ? 1 : 0;
+      }
+    return n;
   };
+  constexpr int PPK = TW ? NWP : (NWP + NKC - 1) / NKC;       // window pieces per window wave and K-step
   int last_win = 0;                   // window pieces this (window) wave issued at the previous phase start
   if (win_wave) {
 #pragma unroll
-    for (int a = 0; a < D; ++a) last_win = issue_window(0, 0, a, tile, smem + a * WIN_BYTES);
+    for (int a = 0; a < D; ++a) last_win = issue_window(0, 0, a, tile, smem + a * WIN_BYTES, 0, NWP);
   } else if (RW) {
     for (int i = 0; i < S; ++i) dma_weights(bring + i * B_BYTES);   // (the launcher checked S <= NBS; same N block for every tile)
   } else {
@@ -430,7 +439,11 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         drain = false;
         if (!RW || j == 0) __builtin_amdgcn_s_barrier();
         if (win_wave) {
-          if (j == 0) last_win = issue_window(it, chunk, D, tile, nwin);
+          if (TW) {
+            if (j == 0) last_win = issue_window(it, chunk, D, tile, nwin, 0, NWP);
+          } else {
+            issue_window(it, chunk, D, tile, nwin, j * PPK, PPK);
+          }
         } else if (!RW) {
           int batch = 0;
           if (s + (NBS - 1) < S) {
