@@ -180,6 +180,8 @@ int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* m
 /* ---- elementwise on bf16 [n] ------------------------------------------------------------ */
 int pp_gelu_fwd(const void* x, void* y, long long n, pp_stream_t s);
 int pp_gelu_bwd(const void* dy, const void* x, void* dx, long long n, pp_stream_t s);
+/* dx = dropout_bwd(dy; p, seed) * gelu'(x): the mask of pp_dropout_bf16 with the same (p, seed), one pass */
+int pp_gelu_bwd_dropout(const void* dy, const void* x, void* dx, long long n, float p, unsigned seed, pp_stream_t s);
 int pp_add_bf16(const void* a, const void* b, void* out, long long n, pp_stream_t s);
 /* dropout with a counter-based mask (seed, element index): y = keep ? x/(1-p) : 0 (+ res).  Calling it again with
  * the same seed on the gradient is the backward pass.  n multiple of 8; x and y may alias. */

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pp_bn_bwd_apply": [P, P, P, P, P, P, P, P, I, P, P, L, I, P],
     "pp_gelu_fwd": [P, P, L, P],
     "pp_gelu_bwd": [P, P, P, L, P],
+    "pp_gelu_bwd_dropout": [P, P, P, L, F, C.c_uint, P],
     "pp_add_bf16": [P, P, P, L, P],
     "pp_dropout_bf16": [P, P, P, L, F, C.c_uint, P],
     "pp_dropout_f32": [P, P, L, F, C.c_uint, P],

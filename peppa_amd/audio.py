@@ -453,10 +453,11 @@ def _enc_backward(enc, t, dout, grads):
             H.dropout_bf16(ds2, dt2, *r.d_ffo)
         _lin_grads(grads, ff.output_dense, r.h, dt2, M, 768, 3072)
         dh = L.linear_dgrad(dt2, M, r.ff2_wt, 3072)
-        if r.d_int[0] > 0:
-            H.dropout_bf16(dh, dh, *r.d_int)
         du = L.empty(dh.shape, bf16, dh)
-        H.gelu_bwd(dh, r.u, du)
+        if r.d_int[0] > 0:
+            H.gelu_bwd_dropout(dh, r.u, du, *r.d_int)      # dropout mask and GELU derivative in one pass
+        else:
+            H.gelu_bwd(dh, r.u, du)
         _lin_grads(grads, ff.intermediate_dense, r.xa, du, M, 3072, 768)
         dxa = L.linear_dgrad(du, M, r.ff1_wt, 768, residual=ds2)
         ds1 = _ln_bwd(grads, layer.layer_norm, dxa, r.s1, r.lnA)

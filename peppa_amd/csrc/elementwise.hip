@@ -448,6 +448,20 @@ __global__ void dropout_bf16_kernel(const bfraw* __restrict__ x, const bfraw* __
     *(uint4*)(y + i * 8) = pack8(f);
   }
 }
+// dx = dropout_bwd(dy) * gelu'(x) in one pass (the feed-forward's intermediate dropout sits right behind its GELU)
+__global__ void gelu_bwd_dropout_kernel(const bfraw* __restrict__ dy, const bfraw* __restrict__ x, bfraw* __restrict__ dx,
+                                        long long nch, uint32_t thr, float scale, uint32_t seed) {
+  GSTRIDE(i, nch) {
+    float f[8], d[8];
+    bool keep[8];
+    unpack8(*(const uint4*)(x + i * 8), f);
+    unpack8(*(const uint4*)(dy + i * 8), d);
+    keep8(seed, i, thr, keep);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = keep[q] ? d[q] * scale * gelu_grad_f(f[q]) : 0.f;
+    *(uint4*)(dx + i * 8) = pack8(d);
+  }
+}
 __global__ void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long long nch, uint32_t thr, float scale,
                                    uint32_t seed) {
   GSTRIDE(i, nch) {
@@ -464,6 +478,14 @@ extern "C" int pp_dropout_bf16(const void* x, const void* res, void* y, long lon
   PP_CHECK_ARG(p >= 0.f && p < 1.f, "pp_dropout_bf16: p=%f", (double)p);
   hipLaunchKernelGGL(dropout_bf16_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)x, (const bfraw*)res, (bfraw*)y, n / 8,
                      (uint32_t)(p * 65536.f + 0.5f), 1.f / (1.f - p), seed);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_gelu_bwd_dropout(const void* dy, const void* x, void* dx, long long n, float p, unsigned seed, pp_stream_t s) {
+  CHK8(n, "pp_gelu_bwd_dropout");
+  PP_CHECK_ARG(p >= 0.f && p < 1.f, "pp_gelu_bwd_dropout: p=%f", (double)p);
+  hipLaunchKernelGGL(gelu_bwd_dropout_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)dy, (const bfraw*)x,
+                     (bfraw*)dx, n / 8, (uint32_t)(p * 65536.f + 0.5f), 1.f / (1.f - p), seed);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -284,6 +284,10 @@ def gelu_bwd(dy, x, dx):
     call("pp_gelu_bwd", _p(dy, bf16), _p(x, bf16), _p(dx, bf16), x.numel(), _s())
 
 
+def gelu_bwd_dropout(dy, x, dx, p, seed):
+    call("pp_gelu_bwd_dropout", _p(dy, bf16), _p(x, bf16), _p(dx, bf16), x.numel(), float(p), int(seed) & 0xffffffff, _s())
+
+
 def add_bf16(a, b, out):
     call("pp_add_bf16", _p(a, bf16), _p(b, bf16), _p(out, bf16), a.numel(), _s())
 

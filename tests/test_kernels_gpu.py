@@ -916,3 +916,25 @@ def test_fused_attention_matches_unfused_and_torch(B, T, p):
 
 def rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def test_gelu_bwd_with_fused_dropout_matches_two_passes():
+    """dx = dropout_bwd(dy) * gelu'(x) in one pass uses the mask of pp_dropout_bf16 for the same (p, seed)."""
+    g = torch.Generator().manual_seed(5)
+    M, N = 333, 3072
+    dy = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    x = (2 * torch.randn(M, N, generator=g)).to(torch.bfloat16).to(DEV)
+    for p_, seed in ((0.1, 1234567), (0.5, 0xFFFFFFFF), (0.0, 7)):
+        masked = torch.empty_like(dy)
+        H.dropout_bf16(dy, masked, p_, seed)
+        two = torch.empty_like(dy)
+        H.gelu_bwd(masked, x, two)
+        one = torch.empty_like(dy)
+        H.gelu_bwd_dropout(dy, x, one, p_, seed)
+        torch.cuda.synchronize()
+        assert torch.equal(one == 0, two == 0) or ((one == 0) ^ (two == 0)).float().mean().item() < 1e-3   # same mask
+        kept = (masked != 0)
+        assert abs(kept.float().mean().item() - (1 - p_)) < 0.01
+        # the two-pass route rounds the masked gradient to bf16 before the GELU factor: one rounding step apart
+        err = (one.float() - two.float()).abs().max().item()
+        assert err <= 2.0 ** -7 * two.float().abs().max().item() + 1e-6, err
