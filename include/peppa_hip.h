@@ -77,6 +77,9 @@ typedef struct pp_igemm_desc {
    * ((n*Ot + rt*os_t + oo_t)*Oh + rh*os_h + oo_h)*Ow + rw*os_w + oo_w of C (and read there from `residual`).
    * Used by the parity-class decomposition of stride-2 data gradients. */
   int omap, Ot, Oh, Ow, os_t, os_h, os_w, oo_t, oo_h, oo_w;
+  /* optional dropout in the epilogue (bf16 outputs with bias / activation / residual): C = dropout(act(AB + bias)) +
+   * residual, with the mask pp_dropout_bf16 would apply to the flat [M][ldc] tensor for the same (p, seed) */
+  float drop_p; unsigned drop_seed;
 } pp_igemm_desc;
 int pp_igemm(const pp_igemm_desc* d, pp_stream_t s);
 

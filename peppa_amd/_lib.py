@@ -30,7 +30,8 @@ class IGemmDesc(C.Structure):
         ("a_s0", C.c_longlong), ("a_s1", C.c_longlong), ("b_s0", C.c_longlong), ("b_s1", C.c_longlong),
         ("c_s0", C.c_longlong), ("c_s1", C.c_longlong), ("bias_s0", C.c_longlong), ("bias_s1", C.c_longlong),
         ("omap", C.c_int), ("Ot", C.c_int), ("Oh", C.c_int), ("Ow", C.c_int), ("os_t", C.c_int), ("os_h", C.c_int),
-        ("os_w", C.c_int), ("oo_t", C.c_int), ("oo_h", C.c_int), ("oo_w", C.c_int)]
+        ("os_w", C.c_int), ("oo_t", C.c_int), ("oo_h", C.c_int), ("oo_w", C.c_int),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint)]
 
 
 class WGradDesc(C.Structure):

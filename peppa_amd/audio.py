@@ -384,27 +384,16 @@ def _enc_forward(enc, feat, B, T, save, training=False):
         ctx, r.P = _attention_fwd(qkv, B, T, Tp, att.scaling, save, r.d_att)
         r.qkv, r.ctx = qkv, ctx
         wf, r.out_wt = w_out
-        if r.d_out[0] > 0:
-            t1 = L.linear_fwd(ctx, M, wf, 768, bias=att.out_proj.bias)
-            s1 = L.empty(t1.shape, bf16, t1)
-            H.dropout_bf16(t1, s1, *r.d_out, res=x)
-        else:
-            s1 = L.linear_fwd(ctx, M, wf, 768, bias=att.out_proj.bias, residual=x)
+        # dropout sits in the GEMM epilogues: s = dropout(x W^T + b) + residual in one kernel
+        s1 = L.linear_fwd(ctx, M, wf, 768, bias=att.out_proj.bias, residual=x, dropout=r.d_out)
         xa, r.lnA = L.layernorm_fwd(s1, layer.layer_norm, layer.layer_norm.eps)
         r.s1, r.xa = s1, xa
         wf, r.ff1_wt = w_ff1
         r.u = L.empty((M, 3072), bf16, feat) if save else None
-        h = L.linear_fwd(xa, M, wf, 3072, bias=ff.intermediate_dense.bias, act=H.ACT_GELU, pre=r.u)
-        if r.d_int[0] > 0:
-            H.dropout_bf16(h, h, *r.d_int)
+        h = L.linear_fwd(xa, M, wf, 3072, bias=ff.intermediate_dense.bias, act=H.ACT_GELU, pre=r.u, dropout=r.d_int)
         r.h = h
         wf, r.ff2_wt = w_ff2
-        if r.d_ffo[0] > 0:
-            t2 = L.linear_fwd(h, M, wf, 768, bias=ff.output_dense.bias)
-            s2 = L.empty(t2.shape, bf16, t2)
-            H.dropout_bf16(t2, s2, *r.d_ffo, res=xa)
-        else:
-            s2 = L.linear_fwd(h, M, wf, 768, bias=ff.output_dense.bias, residual=xa)
+        s2 = L.linear_fwd(h, M, wf, 768, bias=ff.output_dense.bias, residual=xa, dropout=r.d_ffo)
         x, r.lnB = L.layernorm_fwd(s2, layer.final_layer_norm, layer.final_layer_norm.eps)
         r.s2, r.layer = s2, layer
         t.layers.append(r)

@@ -63,6 +63,21 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// ---- counter-based dropout mask (pp_dropout_*, the GEMM epilogue, pp_gelu_bwd_dropout) ------------------------------
+// element i of the flat tensor is kept iff hash16(seed, i) >= p * 65536; chunk = i / 8
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ void keep8(uint32_t seed, long long chunk, uint32_t thr, bool* keep) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t h = mix32((uint32_t)(chunk * 4 + q) * 0x9E3779B9u + seed + (uint32_t)((chunk * 4 + q) >> 32) * 0x7F4A7C15u);
+    keep[2 * q] = (h & 0xffffu) >= thr;
+    keep[2 * q + 1] = (h >> 16) >= thr;
+  }
+}
+
 // ---- wave / block reductions ----------------------------------------------------------
 // sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane, added in the order
 // (r0 + r1) + (r2 + r3) like `v += shfl_xor(v, 16); v += shfl_xor(v, 32)`.  gfx950's v_permlane16_swap / 32_swap do it

@@ -419,18 +419,6 @@ extern "C" int pp_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int 
 // Counter-based mask: element i is kept iff hash16(seed, i) >= p * 65536; the same (seed, i) regenerates the
 // mask in the backward pass, so no mask tensor is stored.  y = keep ? x / (1 - p) : 0  (+ res).
 namespace {
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {
-  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-  return h;
-}
-__device__ __forceinline__ void keep8(uint32_t seed, long long chunk, uint32_t thr, bool* keep) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t h = mix32((uint32_t)(chunk * 4 + q) * 0x9E3779B9u + seed + (uint32_t)((chunk * 4 + q) >> 32) * 0x7F4A7C15u);
-    keep[2 * q] = (h & 0xffffu) >= thr;
-    keep[2 * q + 1] = (h >> 16) >= thr;
-  }
-}
 __global__ void dropout_bf16_kernel(const bfraw* __restrict__ x, const bfraw* __restrict__ res, bfraw* __restrict__ y, long long nch,
                                     uint32_t thr, float scale, uint32_t seed) {
   GSTRIDE(i, nch) {

@@ -325,6 +325,8 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
 
   // ---- epilogue of one finished tile (mb_e, nb_e); defined below the tile loop's helpers -------------------
   const int ncols_store = (p.N + 7) & ~7;
+  const uint32_t drop_thr = FULL ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
+  const float drop_scale = 1.f / (1.f - p.drop_p);
   auto epilogue = [&](const int mb_e, const int nb_e, unsigned char* const ebuf) __attribute__((always_inline)) {
   // FULL = bias / activation / residual / pre-activation copy; otherwise plain store (+ optional
   // BatchNorm column statistics).  Flags are tested once, outside the per-value loops.
@@ -415,6 +417,15 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
             const int n = (int)fdiv(t2, rd.dRt);
             const int rt = (int)t2 - n * g.Rt;
             orow = (((long long)n * p.Ot + rt * p.os_t + p.oo_t) * p.Oh + rh * p.os_h + p.oo_h) * p.Ow + rw * p.os_w + p.oo_w;
+          }
+          if (FULL && drop_thr && Cout == (bfraw*)p.C) {   // (not the pre-activation copy)
+            float x[8];
+            bool keep[8];
+            unpack8(v, x);
+            keep8(p.drop_seed, (c_off + orow * p.ldc + col) >> 3, drop_thr, keep);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = keep[q] ? x[q] * drop_scale : 0.f;
+            v = pack8(x);
           }
           if (FULL && residual) {
             const uint4 rv = *(const uint4*)(residual + c_off + orow * p.ldr + col);
@@ -600,7 +611,7 @@ int launch_wn(const pp_igemm_desc& d, hipStream_t s) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   // persistent grid: as many workgroups as stay resident (LDS-limited: 3 / 2 / 1 per CU) once there are >= 4 waves of
   // tiles, otherwise one tile per workgroup
-  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
+  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;
   const long long resident = 256LL * (WN <= 4 ? 3 : (WN <= 9 ? 2 : 1));
   long long gx = ntiles;
   if (pp_opt_persistent && !full && d.nbatch == 1 && ntiles >= 4 * resident) gx = resident;
@@ -631,7 +642,7 @@ int launch_ring(const pp_igemm_desc& d, hipStream_t s) {
   const long long gx = ntiles < 256 ? ntiles : 256;
   dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(512);
   const RowDiv rd = make_rowdiv(d);
-  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
+  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;
 #define PP_LAUNCH_RING(MODE_, FULL_) \
   hipLaunchKernelGGL((igemm_kernel<WN, MODE_, FULL_, 8, true>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles)
   switch (d.g.mode) {   // (fused epilogues: dense, and conv-forward at 128 columns -- the other conv forms would spill)
@@ -696,6 +707,9 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   } else {
     PP_CHECK_ARG(!d.residual && !d.Cpre && !d.colstats, "pp_igemm: fp32 output supports bias/act only");
   }
+  PP_CHECK_ARG(d.drop_p >= 0.f && d.drop_p < 1.f, "pp_igemm: drop_p=%f", (double)d.drop_p);
+  if (d.drop_p > 0.f) PP_CHECK_ARG(!d.c_fp32 && !d.colstats && !d.omap && d.nbatch == 1,
+                                   "pp_igemm: epilogue dropout needs a plain bf16 output (no fp32 / statistics / row map / batches)");
   if (d.omap) PP_CHECK_ARG(d.g.mode != PP_DENSE && !d.c_fp32 && !d.colstats && d.os_t > 0 && d.os_h > 0 && d.os_w > 0,
                            "pp_igemm: the output row map needs a conv gather and a plain bf16 store");
   if (d.colstats) PP_CHECK_ARG(!d.bias && d.act == PP_ACT_NONE && !d.residual && !d.Cpre && d.nbatch == 1 && d.ldstat >= d.N,
@@ -720,7 +734,7 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
     if (rc_win != 1) return rc_win;
   }
   const int n16 = (d.N + 15) / 16;
-  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre;
+  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;
   if (pp_opt_ring && !d.c_fp32 && d.nbatch == 1 && n16 > 4 && d.K >= 2 * BK) {
     // Ring tiles are 128 or 144 columns wide (whichever pads N less).  Narrow outputs (N <= 64) stay on the
     // register-staged kernel, which measured faster there; so do GEMMs too small to give every CU a 256-row tile.

@@ -520,7 +520,7 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
   const bool conv = g.mode == PP_CONV_FWD || g.mode == PP_CONV_DGRAD;
   // temporal (3,1,1) stride-1 convs with 4, 8 or 16 frames: 256-row tiles = all frames of 64 / 32 / 16 positions
   const int pb = (g.Gt == 4 || g.Gt == 8 || g.Gt == 16) ? 256 / g.Gt : 0;
-  const bool tw_ok = pp_opt_win_temporal && conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE &&
+  const bool tw_ok = pp_opt_win_temporal && conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && d.drop_p == 0.f &&
                      !d.Cpre && !d.omap && g.kt == 3 && g.kh == 1 && g.kw == 1 && g.st == 1 && g.sh == 1 && g.sw == 1 &&
                      g.pt == 1 && g.ph == 0 && g.pw == 0 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && pb > 0 &&
                      (g.Gh * g.Gw) % pb == 0 && d.K == 3 * g.cg && d.M % 256 == 0 &&
@@ -534,7 +534,7 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
     if (g.cg == 144 && n16 <= 4) return launch_win<4, 48, 2, 9, true>(d, s);
     return 1;
   }
-  const bool shape_ok = conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre && !d.omap &&
+  const bool shape_ok = conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre && !d.omap && d.drop_p == 0.f &&
                         g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 &&
                         g.ph == 1 && g.pw == 1 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && g.Gw + 1 <= HALO &&
                         d.K == 9 * g.cg && (g.cg % 64 == 0 || g.cg % 48 == 0) &&

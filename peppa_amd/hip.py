@@ -118,8 +118,10 @@ def _wgrad_family(g):
 
 def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NONE, residual=None, ldr=0,
           Cpre=None, colstats=None, ldstat=0, nbatch=1, inner=1, a_s=(0, 0), b_s=(0, 0), c_s=(0, 0),
-          bias_s=(0, 0), omap=None):
+          bias_s=(0, 0), omap=None, dropout=None):
     d = IGemmDesc()
+    if dropout is not None and dropout[0] > 0:     # (p, seed): the mask of dropout_bf16 on the flat output
+        d.drop_p, d.drop_seed = float(dropout[0]), int(dropout[1]) & 0xffffffff
     d.M, d.N, d.K, d.g = M, N, K, g
     d.A, d.Bt, d.ldb, d.b_rows = _p(A, bf16), _p(Bt, bf16), ldb, b_rows
     d.C, d.ldc, d.c_fp32 = _p(Cout), ldc, int(Cout.dtype == f32)

@@ -290,13 +290,13 @@ class CastBatch:
         self.jobs = []
 
 
-def linear_fwd(x, M, wf, N, *, bias=None, act=H.ACT_NONE, residual=None, pre=None, out=None, out_f32=False):
-    """x bf16 [M][Kp] -> y [M][Np]."""
+def linear_fwd(x, M, wf, N, *, bias=None, act=H.ACT_NONE, residual=None, pre=None, out=None, out_f32=False, dropout=None):
+    """x bf16 [M][Kp] -> y [M][Np] = dropout(act(x W^T + bias)) + residual; `pre` receives the pre-activation."""
     Kp = wf.shape[1]
     Np = cpad(N)
     y = out if out is not None else empty((M, Np), f32 if out_f32 else bf16, x)
     H.igemm(x, wf, y, M, N, Kp, H.gather_dense(x.shape[1]), Kp, Np, b_rows=N, bias=bias, act=act, residual=residual,
-            ldr=Np, Cpre=pre)
+            ldr=Np, Cpre=pre, dropout=dropout)
     return y
 
 

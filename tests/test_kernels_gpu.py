@@ -938,3 +938,39 @@ def test_gelu_bwd_with_fused_dropout_matches_two_passes():
         # the two-pass route rounds the masked gradient to bf16 before the GELU factor: one rounding step apart
         err = (one.float() - two.float()).abs().max().item()
         assert err <= 2.0 ** -7 * two.float().abs().max().item() + 1e-6, err
+
+
+@pytest.mark.parametrize("M,N,K,act,with_res", [(1274, 768, 768, "none", True), (7296, 3072, 768, "gelu", False),
+                                                 (300, 768, 3072, "none", True), (77, 96, 64, "none", False)])
+def test_gemm_epilogue_dropout_matches_separate_dropout(M, N, K, act, with_res):
+    """C = dropout(act(x W^T + b)) + residual in the GEMM epilogue carries the very mask pp_dropout_bf16 applies to the flat
+    output for the same (p, seed) -- the backward pass regenerates it from (seed, element index)."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, L.cpad(N), generator=g).to(torch.bfloat16).to(DEV) if with_res else None
+    wf, _ = L.prep_linear(w)
+    a = H.ACT_GELU if act == "gelu" else H.ACT_NONE
+    p_, seed = 0.1, 0xC0FFEE
+    plain = L.linear_fwd(x, M, wf, N, bias=b, act=a)
+    two = torch.empty_like(plain)
+    H.dropout_bf16(plain, two, p_, seed, res=res)
+    pre = torch.empty_like(plain) if act == "gelu" else None
+    one = L.linear_fwd(x, M, wf, N, bias=b, act=a, residual=res, pre=pre, dropout=(p_, seed))
+    torch.cuda.synchronize()
+    mask_ref = torch.empty_like(plain)
+    H.dropout_bf16(plain, mask_ref, p_, seed)                 # (without the residual: zero <=> dropped)
+    torch.cuda.synchronize()
+    one, two, plain = one[:, :N].float(), two[:, :N].float(), plain[:, :N].float()
+    r = res[:, :N].float() if with_res else torch.zeros_like(one)
+    dropped = (mask_ref[:, :N] == 0) & (plain != 0)
+    assert abs(dropped.float().mean().item() - p_) < 0.02
+    assert torch.equal((one - r)[dropped], torch.zeros_like(one)[dropped])          # same elements are zeroed
+    scale = two.abs().max().item()
+    assert (one - two).abs().max().item() <= 2.0 ** -6 * scale          # the two-pass route rounds once more
+    if pre is not None:       # the pre-activation copy is never masked
+        nodrop_pre = torch.empty_like(pre)
+        L.linear_fwd(x, M, wf, N, bias=b, act=a, pre=nodrop_pre)
+        torch.cuda.synchronize()
+        assert torch.equal(pre, nodrop_pre)
