@@ -77,42 +77,44 @@ struct AttnArgs {
 };
 
 // load one [T][64] head slice (row stride ld elements) into a zero-padded [128][64] LDS tile
+template <int NTH>
 __device__ __forceinline__ void load_tile(unsigned char* tile, const bfraw* src, int ld, int T, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+  for (int i = 0; i < TT / (NTH / 8); ++i) {
+    const int row = (tid >> 3) + (NTH / 8) * i, ch = tid & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < T) v = *(const uint4*)(src + (long long)row * ld + ch * 8);
     *(uint4*)(tile + row * QS + ch * 16) = v;
   }
 }
 
-// scores of this wave's 32 query rows against all 128 keys, softmax, dropout: P (fp32, registers) and Pd (bf16, LDS)
+// scores of this wave's 16 MT query rows against all 128 keys, softmax, dropout: P (fp32, registers) and Pd (bf16, LDS)
+template <int MT>
 __device__ __forceinline__ void scores_softmax(const AttnArgs& p, const unsigned char* Qs, const unsigned char* Ks,
-                                               unsigned char* Ps, int bh, int wave, int lane, f32x4 (&P)[2][8]) {
+                                               unsigned char* Ps, int bh, int wave, int lane, f32x4 (&P)[MT][8]) {
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) P[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 aq[2];
+    bf16x8 aq[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) aq[mt] = frag_rowmajor(Qs, QS, wave * 32 + mt * 16, ks * 32, lane);
+    for (int mt = 0; mt < MT; ++mt) aq[mt] = frag_rowmajor(Qs, QS, wave * (16 * MT) + mt * 16, ks * 32, lane);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
       const bf16x8 bk = frag_rowmajor(Ks, QS, nt * 16, ks * 32, lane);
-      P[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[0], bk, P[0][nt], 0, 0, 0);
-      P[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[1], bk, P[1][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) P[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[mt], bk, P[mt][nt], 0, 0, 0);
     }
   }
-  // accumulator layout: column j = fr + 16 nt, rows t = 32 wave + 16 mt + 4 fq + r
+  // accumulator layout: column j = fr + 16 nt, rows t = 16 MT wave + 16 mt + 4 fq + r
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int t = wave * 32 + mt * 16 + fq * 4 + r;
+      const int t = wave * (16 * MT) + mt * 16 + fq * 4 + r;
       float mx = -3.0e38f;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
@@ -162,12 +164,12 @@ __global__ __launch_bounds__(256, 1) void attention_fwd_kernel(const AttnArgs p)
   const int bh = blockIdx.x, b = bh / p.Hn, h = bh % p.Hn;
   const int D = p.Hn * DH, D3 = 3 * D;
   const bfraw* base = p.qkv + (long long)b * p.T * D3 + h * DH;
-  load_tile(Qs, base, D3, p.T, tid);
-  load_tile(Ks, base + D, D3, p.T, tid);
-  load_tile(Vs, base + 2 * D, D3, p.T, tid);
+  load_tile<256>(Qs, base, D3, p.T, tid);
+  load_tile<256>(Ks, base + D, D3, p.T, tid);
+  load_tile<256>(Vs, base + 2 * D, D3, p.T, tid);
   __syncthreads();
   f32x4 P[2][8];
-  scores_softmax(p, Qs, Ks, Ps, bh, wave, lane, P);
+  scores_softmax<2>(p, Qs, Ks, Ps, bh, wave, lane, P);
   __syncthreads();   // (only this wave's rows of Pd are read below; the barrier also orders the 2-byte stores)
   // O^T[d][t] = sum_j V[j][d] Pd[t][j]: first operand indexed by d (V is k-major), second by t (Pd row-major)
   f32x4 O[4][2];
@@ -193,7 +195,10 @@ __global__ __launch_bounds__(256, 1) void attention_fwd_kernel(const AttnArgs p)
     for (int mt = 0; mt < 2; ++mt) store_t(out, D, wave * 32 + mt * 16 + fr, p.T, nd * 16 + fq * 4, O[nd][mt]);
 }
 
-__global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const AttnArgs p) {
+// Eight waves, one 16-row tile of queries each (BMT = 1): with four waves of two tiles the kernel ran one wave per SIMD and
+// every phase (LDS fragment reads -> MFMA chain -> exp / reductions) was exposed; two waves per SIMD overlap them.
+constexpr int BMT = 1, BNT = 64 * (8 / BMT);
+__global__ __launch_bounds__(BNT, 1) void attention_bwd_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * QK_BYTES + 2 * P_BYTES];
   unsigned char* Qs = smem;
   unsigned char* Ks = smem + QK_BYTES;
@@ -206,37 +211,37 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const AttnArgs p)
   const int bh = blockIdx.x, b = bh / p.Hn, h = bh % p.Hn;
   const int D = p.Hn * DH, D3 = 3 * D;
   const bfraw* base = p.qkv + (long long)b * p.T * D3 + h * DH;
-  load_tile(Qs, base, D3, p.T, tid);
-  load_tile(Ks, base + D, D3, p.T, tid);
-  load_tile(Vs, base + 2 * D, D3, p.T, tid);
-  load_tile(Os, p.dctx + (long long)b * p.T * D + h * DH, D, p.T, tid);
+  load_tile<BNT>(Qs, base, D3, p.T, tid);
+  load_tile<BNT>(Ks, base + D, D3, p.T, tid);
+  load_tile<BNT>(Vs, base + 2 * D, D3, p.T, tid);
+  load_tile<BNT>(Os, p.dctx + (long long)b * p.T * D + h * DH, D, p.T, tid);
   __syncthreads();
-  f32x4 P[2][8];
-  scores_softmax(p, Qs, Ks, Ps, bh, wave, lane, P);
+  f32x4 P[BMT][8];
+  scores_softmax<BMT>(p, Qs, Ks, Ps, bh, wave, lane, P);
 
   // dP[t][j] = sum_d dO[t][d] V[j][d]  (both row-major in d); through the dropout; dS = scale * P o (dPd - rowsum(dPd o P))
-  f32x4 dP[2][8];
+  f32x4 dP[BMT][8];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < BMT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) dP[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 ao[2];
+    bf16x8 ao[BMT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) ao[mt] = frag_rowmajor(Os, QS, wave * 32 + mt * 16, ks * 32, lane);
+    for (int mt = 0; mt < BMT; ++mt) ao[mt] = frag_rowmajor(Os, QS, wave * (16 * BMT) + mt * 16, ks * 32, lane);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
       const bf16x8 bv = frag_rowmajor(Vs, QS, nt * 16, ks * 32, lane);
-      dP[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[0], bv, dP[0][nt], 0, 0, 0);
-      dP[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[1], bv, dP[1][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < BMT; ++mt) dP[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[mt], bv, dP[mt][nt], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < BMT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int t = wave * 32 + mt * 16 + fq * 4 + r;
+      const int t = wave * (16 * BMT) + mt * 16 + fq * 4 + r;
       float dot = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
@@ -259,65 +264,67 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const AttnArgs p)
   bfraw* dq = p.dqkv + (long long)b * p.T * D3 + h * DH;
   bfraw* dk = dq + D;
   bfraw* dv = dq + 2 * D;
-  f32x4 acc[4][2];
+  f32x4 acc[4][BMT];
   auto zero = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int nd = 0; nd < 4; ++nd) acc[nd][0] = acc[nd][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
   // dV^T[d][j] = sum_t dO[t][d] Pd[t][j]   (both k-major in t)
   zero();
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
-    bf16x8 bp[2];
+    bf16x8 bp[BMT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) bp[mt] = frag_kmajor(Ps, PS, wave * 32 + mt * 16, kt * 32, lane);
+    for (int mt = 0; mt < BMT; ++mt) bp[mt] = frag_kmajor(Ps, PS, wave * (16 * BMT) + mt * 16, kt * 32, lane);
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) {
       const bf16x8 ao = frag_kmajor(Os, QS, nd * 16, kt * 32, lane);
-      acc[nd][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp[0], acc[nd][0], 0, 0, 0);
-      acc[nd][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp[1], acc[nd][1], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp[mt], acc[nd][mt], 0, 0, 0);
     }
   }
 #pragma unroll
   for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) store_t(dv, D3, wave * 32 + mt * 16 + fr, p.T, nd * 16 + fq * 4, acc[nd][mt]);
+    for (int mt = 0; mt < BMT; ++mt) store_t(dv, D3, wave * (16 * BMT) + mt * 16 + fr, p.T, nd * 16 + fq * 4, acc[nd][mt]);
   // dQ^T[d][t] = sum_j K[j][d] dS[t][j]    (K k-major in j, dS row-major in j)
   zero();
 #pragma unroll
   for (int kj = 0; kj < 4; ++kj) {
-    bf16x8 bs[2];
+    bf16x8 bs[BMT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) bs[mt] = frag_rowmajor(Ss, PS, wave * 32 + mt * 16, kj * 32, lane);
+    for (int mt = 0; mt < BMT; ++mt) bs[mt] = frag_rowmajor(Ss, PS, wave * (16 * BMT) + mt * 16, kj * 32, lane);
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) {
       const bf16x8 ak = frag_kmajor(Ks, QS, nd * 16, kj * 32, lane);
-      acc[nd][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bs[0], acc[nd][0], 0, 0, 0);
-      acc[nd][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bs[1], acc[nd][1], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bs[mt], acc[nd][mt], 0, 0, 0);
     }
   }
 #pragma unroll
   for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) store_t(dq, D3, wave * 32 + mt * 16 + fr, p.T, nd * 16 + fq * 4, acc[nd][mt]);
+    for (int mt = 0; mt < BMT; ++mt) store_t(dq, D3, wave * (16 * BMT) + mt * 16 + fr, p.T, nd * 16 + fq * 4, acc[nd][mt]);
   // dK^T[d][j] = sum_t Q[t][d] dS[t][j]    (both k-major in t)
   zero();
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
-    bf16x8 bs[2];
+    bf16x8 bs[BMT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) bs[mt] = frag_kmajor(Ss, PS, wave * 32 + mt * 16, kt * 32, lane);
+    for (int mt = 0; mt < BMT; ++mt) bs[mt] = frag_kmajor(Ss, PS, wave * (16 * BMT) + mt * 16, kt * 32, lane);
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) {
       const bf16x8 aq = frag_kmajor(Qs, QS, nd * 16, kt * 32, lane);
-      acc[nd][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bs[0], acc[nd][0], 0, 0, 0);
-      acc[nd][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bs[1], acc[nd][1], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bs[mt], acc[nd][mt], 0, 0, 0);
     }
   }
 #pragma unroll
   for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) store_t(dk, D3, wave * 32 + mt * 16 + fr, p.T, nd * 16 + fq * 4, acc[nd][mt]);
+    for (int mt = 0; mt < BMT; ++mt) store_t(dk, D3, wave * (16 * BMT) + mt * 16 + fr, p.T, nd * 16 + fq * 4, acc[nd][mt]);
 }
 
 int check(const char* who, const void* qkv, int B, int T, int Hn, float p) {
@@ -356,7 +363,7 @@ extern "C" int pp_attention_bwd(const void* qkv, const void* dctx, int B, int T,
   AttnArgs a = make_args(qkv, T, heads, scale, drop_p, seed);
   a.dctx = (const bfraw*)dctx;
   a.dqkv = (bfraw*)dqkv;
-  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)s, a);
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * heads), dim3(BNT), 0, (hipStream_t)s, a);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
