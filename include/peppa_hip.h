@@ -296,10 +296,14 @@ typedef struct pp_tensor_list {
   float* const* v;
   const long long* numel;
 } pp_tensor_list; /* the pointer arrays live in DEVICE memory */
-/* chunk table (device): chunk c covers tensor chunk_tensor[c], elements [chunk_off[c], +chunk) */
+/* chunk table (device): chunk c covers tensor chunk_tensor[c], elements [chunk_off[c], +chunk).
+ * lr_per_tensor (device, [n_tensors], optional): scheduled learning rate of each tensor -- the reference keeps a step
+ * count per tensor (pig/optimization.py:120-128), and tensors that skipped steps (LayerDrop) lag behind in the schedule;
+ * with it every tensor of a parameter group goes into one launch.  NULL: lr_scheduled for all. */
 int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off,
                      int n_chunks, int chunk, float* norms /* [n_tensors] scratch */, float lr_scheduled,
-                     float b1, float b2, float eps, float weight_decay, float max_grad_norm, pp_stream_t s);
+                     float b1, float b2, float eps, float weight_decay, float max_grad_norm,
+                     const float* lr_per_tensor, pp_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -113,7 +113,7 @@ SIGNATURES = {
     "pp_cosine_matrix": [P, P, I, I, I, P, P, P],
     "pp_contrastive_fwd": [P, I, F, P, P, P],
     "pp_triplet_accuracy": [P, P, P, I, I, I, P, P],
-    "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P],
+    "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P, P],
 }
 _RESTYPE = {"pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z}
 _NO_STATUS = set(_RESTYPE) | {"pp_version"}

@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const pp_tensor_list tl, con
 __global__ __launch_bounds__(256) void bertadam_kernel(const pp_tensor_list tl, const int* __restrict__ chunk_tensor,
                                                        const long long* __restrict__ chunk_off, int chunk,
                                                        const float* __restrict__ norms, float lr, float b1, float b2, float eps,
-                                                       float wd, float max_norm) {
+                                                       float wd, float max_norm, const float* __restrict__ lr_t) {
   const int t = chunk_tensor[blockIdx.x];
+  if (lr_t) lr = lr_t[t];   // per-tensor scheduled learning rate (tensors whose step counts differ share one launch)
   const long long off = chunk_off[blockIdx.x];
   const long long n = tl.numel[t];
   float* p = tl.p[t];
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const pp_tensor_list tl, 
 
 extern "C" int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off, int n_chunks,
                                 int chunk, float* norms, float lr_scheduled, float b1, float b2, float eps, float weight_decay,
-                                float max_grad_norm, pp_stream_t s) {
+                                float max_grad_norm, const float* lr_per_tensor, pp_stream_t s) {
   PP_CHECK_ARG(tl && tl->n_tensors > 0 && n_chunks > 0 && chunk > 0 && norms, "pp_bertadam_step: bad arguments");
   hipStream_t st = (hipStream_t)s;
   if (max_grad_norm > 0.f) {
@@ -62,7 +63,7 @@ extern "C" int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tenso
     hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms);
   }
   hipLaunchKernelGGL(bertadam_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms, lr_scheduled,
-                     b1, b2, eps, weight_decay, max_grad_norm);
+                     b1, b2, eps, weight_decay, max_grad_norm, lr_per_tensor);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

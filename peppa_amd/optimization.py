@@ -7,6 +7,7 @@ decoupled weight decay on every tensor, schedule multiplier from the per-tensor 
 elementwise kernels per parameter tensor."""
 import math
 import logging
+import numpy as np
 import torch
 from torch.optim import Optimizer
 from torch.optim.optimizer import required
@@ -80,16 +81,20 @@ class BertAdam(Optimizer):
         return lr
 
     def _chunks(self, numels, device):
+        """Chunk tables of one launch: chunk c covers tensor ct[c], elements [co[c], co[c] + _CHUNK).  Built with numpy
+        and uploaded from pinned memory without blocking: which tensors take part changes from step to step (LayerDrop
+        leaves the skipped layers without gradients), and a pageable `torch.tensor(..., device=)` here made the host
+        wait for the whole backward pass every time the pattern was new."""
         key = (tuple(numels), str(device))
         if key not in self._chunk_cache:
-            ct, co = [], []
-            for i, n in enumerate(numels):
-                for off in range(0, n, _CHUNK):
-                    ct.append(i)
-                    co.append(off)
-            self._chunk_cache[key] = (torch.tensor(ct, dtype=torch.int32, device=device),
-                                      torch.tensor(co, dtype=torch.int64, device=device), len(ct),
-                                      torch.empty(len(numels), dtype=f32, device=device))
+            counts = (np.asarray(numels, dtype=np.int64) + _CHUNK - 1) // _CHUNK
+            ct = np.repeat(np.arange(len(numels), dtype=np.int32), counts)
+            starts = np.cumsum(counts) - counts
+            co = (np.arange(int(counts.sum()), dtype=np.int64) - np.repeat(starts, counts)) * _CHUNK
+            up = lambda a: torch.from_numpy(a).pin_memory().to(device, non_blocking=True)
+            if len(self._chunk_cache) > 256:      # (patterns recur; the cap only guards against unbounded growth)
+                self._chunk_cache.clear()
+            self._chunk_cache[key] = (up(ct), up(co), int(counts.sum()), torch.empty(len(numels), dtype=f32, device=device))
         return self._chunk_cache[key]
 
     def step(self, closure=None):
@@ -98,7 +103,7 @@ class BertAdam(Optimizer):
             loss = closure()
         warned = False
         for group in self.param_groups:
-            buckets = {}  # same step count and device -> one fused launch
+            per_device = {}  # every tensor of the group with a gradient, per device: ONE fused launch pair
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -111,19 +116,26 @@ class BertAdam(Optimizer):
                     state['step'] = 0
                     state['next_m'] = torch.zeros_like(p.data)
                     state['next_v'] = torch.zeros_like(p.data)
-                buckets.setdefault((state['step'], p.device), []).append(p)
-            for (step, device), ps in buckets.items():
-                if (group['t_total'] != -1 and group['schedule'] == "warmup_linear" and
-                        step / group['t_total'] > 1. and not warned):
-                    logger.warning("Training beyond specified 't_total' steps with schedule '{}'.".format(group['schedule']))
-                    warned = True
+                per_device.setdefault(p.device, []).append(p)
+            for device, ps in per_device.items():
+                # the reference schedules every tensor by its OWN step count (pig/optimization.py:160-170): tensors that
+                # skipped steps lag behind, so the scheduled learning rate is per tensor
+                lrs = []
+                for p in ps:
+                    step = self.state[p]['step']
+                    if (group['t_total'] != -1 and group['schedule'] == "warmup_linear" and
+                            step / group['t_total'] > 1. and not warned):
+                        logger.warning("Training beyond specified 't_total' steps with schedule '{}'.".format(group['schedule']))
+                        warned = True
+                    lrs.append(self._lr(group, step))
                 gs = [p.grad.data if p.grad.is_contiguous() else p.grad.data.contiguous() for p in ps]
                 ms = [self.state[p]['next_m'] for p in ps]
                 vs = [self.state[p]['next_v'] for p in ps]
                 tl, keep = H.make_tensor_list([p.data for p in ps], gs, ms, vs, device)
+                lr_t = torch.tensor(lrs, dtype=f32).pin_memory().to(device, non_blocking=True)
                 ct, co, n_chunks, norms = self._chunks([p.numel() for p in ps], device)
-                H.bertadam_step(tl, ct, co, n_chunks, _CHUNK, norms, float(self._lr(group, step)), group['b1'],
-                                group['b2'], group['e'], group['weight_decay'], group['max_grad_norm'])
+                H.bertadam_step(tl, ct, co, n_chunks, _CHUNK, norms, float(lrs[0]), group['b1'], group['b2'], group['e'],
+                                group['weight_decay'], group['max_grad_norm'], lr_t=lr_t)
                 for p in ps:
                     self.state[p]['step'] += 1
         return loss

@@ -440,3 +440,34 @@ def test_data_parallel_machinery_single_rank():
     finally:
         os.environ["PEPPA_FORCE_DIST"] = "0"
         dist.destroy_process_group()
+
+
+def test_optimizer_keeps_a_step_count_per_tensor():
+    """Tensors that miss steps (LayerDrop leaves a skipped layer without gradients) lag behind in the warm-up schedule,
+    exactly as in the reference, although every tensor of a step goes through ONE fused launch."""
+    g = torch.Generator().manual_seed(9)
+    shapes = [(7,), (130, 70), (3, 5, 2), (70000,), (1,)]
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g).to(DEV)) for s in shapes]
+    cpu_params = [p.detach().cpu().clone() for p in params]
+    kw = dict(lr=1e-2, warmup=0.3, t_total=10)
+    optim = pig.optimization.BertAdam(params, **kw)
+    st = {}
+    skip = {1: {0, 3}, 2: {3}, 4: {1, 2, 4}}          # step -> tensors without a gradient in that step
+    for step in range(6):
+        grads = []
+        for i, p in enumerate(params):
+            if i in skip.get(step, ()):
+                p.grad = None
+                grads.append(None)
+            else:
+                gr = torch.randn(*shapes[i], generator=g) * (5.0 if i == 1 else 0.2)
+                p.grad = gr.to(DEV)
+                grads.append(gr)
+        optim.step()
+        O.bertadam_step(cpu_params, grads, st, **kw)
+        torch.cuda.synchronize()
+        for i, (p, pc) in enumerate(zip(params, cpu_params)):
+            d = (p.detach().cpu() - pc).abs().max().item()
+            assert d <= 1e-6 + 1e-5 * pc.abs().max().item(), (i, step, d)
+    assert [optim.state[p]["step"] for p in params] == [5, 5, 5, 4, 5]
+    assert optim.get_lr()[3] != optim.get_lr()[0]
