@@ -4,7 +4,7 @@ loss + backward + gradient all-reduce + BertAdam) on hparams_base shapes (BASELI
 B=64 clips per GPU of 16x112x112 video + 2.3 s @ 16 kHz audio, bf16 compute, synthetic data,
 random-init weights.  One process per GPU (torch.distributed / RCCL); weak scaling.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 30 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
@@ -33,8 +33,8 @@ HBM_PEAK = 8.0e12
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=112)
@@ -184,6 +184,20 @@ def main():
             roof_obj["isolated"] = {"achieved": round(iso[0] / iso[1] / 1e12, 2), "avg_us": round(iso[1] / iso[2] * 1e6, 1),
                                     "frac": round(iso[0] / iso[1] / MFMA_BF16_PEAK, 4),
                                     "note": "same kernel family, one extra step with stream overlap off"}
+    # forward-only throughput (SURVEY 8d asks for it next to the training number): both encoders + loss, no graph, the
+    # same batch; rank 0's rate x world (the forward pass has no collective)
+    fwd_pairs = None
+    if True:
+        with torch.no_grad():
+            for _ in range(2):
+                net.loss(*net.encode_pair(batch.video, batch.audio))
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            nf = max(5, args.steps // 2)
+            for _ in range(nf):
+                net.loss(*net.encode_pair(batch.video, batch.audio))
+            torch.cuda.synchronize()
+            fwd_pairs = world * args.batch * nf / (time.perf_counter() - tf0)
     out = {
         "metric": "clip-pairs/sec (A+V encode + triplet loss), hparams_base", "value": round(value, 2),
         "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -193,7 +207,8 @@ def main():
                                f"{args.samples / 16000:.1f} s@16kHz audio, batch {args.batch}/GPU (BASELINE configs[1])",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}",
                    "step_tflops": round(GF_TRAIN_PER_PAIR * world * args.batch / (ms * 1e-3) / 1e12, 1),
-                   "loss": round(float(loss.item()), 5)},
+                   "loss": round(float(loss.item()), 5),
+                   "forward_only_pairs_per_s": None if fwd_pairs is None else round(fwd_pairs, 1)},
         "roofline": roof_obj,
     }
     if use_dist:
