@@ -138,10 +138,18 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    trace = os.environ.get("PEPPA_BENCH_TRACE")     # per-step GPU times on stderr (events; no extra syncs)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if trace else None
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if trace:
+            marks[i].record()
         loss = step(args.warmup + i)
+    if trace:
+        marks[args.steps].record()
     torch.cuda.synchronize()
+    if trace and rank == 0:
+        print("per-step ms:", " ".join(f"{marks[i].elapsed_time(marks[i + 1]):.1f}" for i in range(args.steps)), file=sys.stderr)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
