@@ -151,6 +151,9 @@ int pp_maxpool3x3s2_fwd(const void* x, void* y, int N, int H, int W, int Cp, pp_
 int pp_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int Cp, pp_stream_t s);
 
 /* ---- BatchNorm3d (train mode) : torchvision BN layers inside R3DEncoder ---------------- */
+/* out[2][ld] = sum over the nblk rows of a partials table [nblk][2][ld] (ws: [64][2][ld] scratch).  With SyncBN the
+ * caller all-reduces `out` across ranks (RCCL, SUM) and finalizes it as a one-row table with the global count. */
+int pp_partials_sum(const float* partials, int nblk, int ld, float* ws, float* out, pp_stream_t s);
 /* reduce igemm colstats partials -> mean, rstd, scale=gamma*rstd, shift=beta-mean*scale;
  * updates running stats (momentum, unbiased var). C real channels, Cp padded (scale/shift=0). */
 int pp_bn_finalize(const float* partials, int nblk, int ldstat, long long count, int C, int Cp,

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pp_video_normalize_u8_ndhwc": [P, P, I, I, I, I, C.POINTER(F), C.POINTER(F), P],
     "pp_maxpool3x3s2_fwd": [P, P, I, I, I, I, P],
     "pp_maxpool3x3s2_bwd": [P, P, P, I, I, I, I, P],
+    "pp_partials_sum": [P, I, I, P, P, P],
     "pp_bn_finalize": [P, I, I, L, I, I, P, P, F, F, P, P, P, P, P, P, P, P],
     "pp_colstats_bf16": [P, L, I, P, I, P],
     "pp_bn_eval_affine": [P, P, P, P, F, I, I, P, P, P],

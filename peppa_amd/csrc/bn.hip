@@ -323,6 +323,20 @@ extern "C" int pp_colstats_bf16(const void* y, long long M, int Cp, float* parti
   return PP_OK;
 }
 
+// column sums of a partials table: out[2][ld] = sum_b partials[b][2][ld] (the quantity SyncBN all-reduces across ranks)
+extern "C" int pp_partials_sum(const float* partials, int nblk, int ld, float* ws /* [64][2][ld] */, float* out,
+                               pp_stream_t s) {
+  PP_CHECK_ARG(partials && out && ws && nblk > 0 && ld > 0, "pp_partials_sum: bad arguments");
+  const int nslice = nblk > 64 ? 64 : 1, per_slice = (nblk + nslice - 1) / nslice;
+  float* first = nslice > 1 ? ws : out;
+  hipLaunchKernelGGL(partials_reduce_kernel, dim3((ld + 15) / 16, nslice), dim3(256), 0, (hipStream_t)s, partials, nblk, ld,
+                     per_slice, first);
+  if (nslice > 1)
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((ld + 15) / 16, 1), dim3(256), 0, (hipStream_t)s, ws, nslice, ld, nslice, out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
 extern "C" int pp_bn_finalize(const float* partials, int nblk, int ldstat, long long count, int C, int Cp,
                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, float* mean, float* rstd, float* scale, float* shift, float* ws,

@@ -185,6 +185,19 @@ class GradBuckets:
         self.reset()
 
 
+def enable_sync_bn(on=True):
+    """BatchNorm statistics over the global batch (SURVEY 8e `SyncBN` option; yaml: `mi355x: {sync_bn: true}`): every
+    BN layer all-reduces its (sum, sum of squares) row in the forward pass and its (sum g, sum g*xhat) row in the
+    backward pass -- two [2][C] fp32 RCCL all-reduces per layer and step.  Off by default: the reference trains under
+    Lightning DDP without `sync_batchnorm`, i.e. with per-rank statistics."""
+    from . import layers as L
+    if on and dist.is_available() and dist.is_initialized():
+        L.SYNC_BN_REDUCE = lambda t: dist.all_reduce(t)
+        L.SYNC_BN_WORLD = dist.get_world_size()
+    else:
+        L.SYNC_BN_REDUCE, L.SYNC_BN_WORLD = None, 1
+
+
 def default_buckets(net, device):
     """Bucket layout for PeppaPig: the video tower by stage, the wav2vec2 feature extractor, one bucket per
     transformer layer (so LayerDrop leaves whole buckets empty instead of forcing a late, unoverlapped reduce) and the
@@ -215,4 +228,5 @@ def default_buckets(net, device):
         stages.setdefault(key, []).append(p)
     for key in sorted(stages):
         groups.append((f"video.{key}", stages[key]))
+    enable_sync_bn(bool(getattr(net, "config", {}).get("mi355x", {}).get("sync_bn", False)))
     return GradBuckets([(n, ps) for n, ps in groups if any(p.requires_grad for p in ps)], device)

@@ -249,6 +249,10 @@ def bn_finalize(partials, nblk, ldstat, count, Cn, Cp, gamma, beta, eps, momentu
          _p(ws, f32), _s())
 
 
+def partials_sum(partials, nblk, ld, ws, out):
+    call("pp_partials_sum", _p(partials, f32), nblk, ld, _p(ws, f32), _p(out, f32), _s())
+
+
 def bn_eval_affine(gamma, beta, rmean, rvar, eps, Cn, Cp, scale, shift):
     call("pp_bn_eval_affine", _p(gamma, f32), _p(beta, f32), _p(rmean, f32), _p(rvar, f32), eps, Cn, Cp, _p(scale, f32),
          _p(shift, f32), _s())

@@ -213,6 +213,21 @@ class BNSaved:
     __slots__ = ("mean", "rstd", "scale", "shift", "count", "C", "Cp")
 
 
+# SyncBN (SURVEY 8e, off by default like the reference's DDP run): batch statistics over ALL ranks.  SYNC_BN_REDUCE is the
+# collective -- `torch.distributed.all_reduce(t)` (RCCL, SUM, in place) -- and SYNC_BN_WORLD the number of ranks;
+# peppa_amd.dist.enable_sync_bn() sets both (tests plug in a stand-in to play two ranks in one process).
+SYNC_BN_REDUCE = None
+SYNC_BN_WORLD = 1
+
+
+def _global_sums(partials, nblk, Cp):
+    """[nblk][2][Cp] per-rank partial sums -> [1][2][Cp] sums over every rank's rows (one small all-reduce)."""
+    tot = empty((1, 2, Cp), f32, partials)
+    H.partials_sum(partials, nblk, Cp, empty((64, 2, Cp), f32, partials), tot)
+    SYNC_BN_REDUCE(tot)
+    return tot
+
+
 def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momentum=0.1, update_running=True):
     """z = relu?(bn(y) (+residual)); `bn` has .weight .bias .running_mean .running_var."""
     C = bn.weight.numel()
@@ -223,6 +238,9 @@ def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momen
     if partials is None:  # eval mode: running statistics (no backward through this path)
         H.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, eps, C, Cp, sv.scale, sv.shift)
     else:
+        if SYNC_BN_REDUCE is not None:      # statistics of the global batch: sums and count over all ranks
+            partials, nblk, count = _global_sums(partials, nblk, Cp), 1, count * SYNC_BN_WORLD
+            sv.count = count
         ws = empty((64, 2, Cp), f32, y) if nblk > 256 else None
         H.bn_finalize(partials, nblk, Cp, count, C, Cp, bn.weight, bn.bias, eps, momentum,
                       bn.running_mean if update_running else None, bn.running_var if update_running else None,
@@ -242,6 +260,11 @@ def bn_bwd(dz, y, z, sv, gamma, *, relu, want_dres=False):
     dgamma, dbeta = empty((sv.C,), f32, y), empty((sv.C,), f32, y)
     coef = empty((3, Cp), f32, y)
     H.bn_bwd_finalize(partials, nblk, sv.count, sv.C, Cp, gamma, sv.rstd, dgamma, dbeta, coef)
+    if SYNC_BN_REDUCE is not None:
+        # dgamma / dbeta stay this rank's sums (the data-parallel all-reduce adds the ranks up); the coefficients of dy
+        # -- the means of g and g * xhat -- are those of the global batch (sv.count already is the global count)
+        scratch = empty((2, sv.C), f32, y)
+        H.bn_bwd_finalize(_global_sums(partials, nblk, Cp), 1, sv.count, sv.C, Cp, gamma, sv.rstd, scratch[0], scratch[1], coef)
     dy = empty(y.shape, bf16, y)
     dres = empty(y.shape, bf16, y) if want_dres else None
     H.bn_bwd_apply(dz, y, z, sv.mean, sv.rstd, coef, sv.scale, sv.shift, relu, dy, dres, M, Cp)

@@ -974,3 +974,86 @@ def test_gemm_epilogue_dropout_matches_separate_dropout(M, N, K, act, with_res):
         L.linear_fwd(x, M, wf, N, bias=b, act=a, pre=nodrop_pre)
         torch.cuda.synchronize()
         assert torch.equal(pre, nodrop_pre)
+
+
+def test_sync_bn_two_ranks_in_one_process_match_the_global_batch():
+    """SyncBN (SURVEY 8e option): with the (sum, sum of squares) rows of the forward pass and the (sum g, sum g*xhat) rows of
+    the backward pass summed over ranks, every rank reproduces BatchNorm over the global batch.  The all-reduce is played
+    by a stand-in that adds the other half's recorded row."""
+    class BN:
+        pass
+    g = torch.Generator().manual_seed(17)
+    M, C = 2 * 1536, 144
+    Cp = L.cpad(C)
+    y = torch.zeros(M, Cp)
+    y[:, :C] = torch.randn(M, C, generator=g) * torch.linspace(0.5, 2.0, C) + torch.linspace(-1, 1, C)
+    y[: M // 2] += 0.7                       # the halves have different statistics
+    dz = torch.zeros(M, Cp)
+    dz[:, :C] = torch.randn(M, C, generator=g)
+    y, dz = y.to(torch.bfloat16).to(DEV), dz.to(torch.bfloat16).to(DEV)
+
+    def make_bn():
+        bn = BN()
+        bn.weight = (1 + 0.1 * torch.arange(C, dtype=torch.float32)).to(DEV) / 8
+        bn.bias = torch.linspace(-0.5, 0.5, C).to(DEV)
+        bn.running_mean, bn.running_var = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        return bn
+
+    def stats(t):
+        nb = (t.shape[0] + 127) // 128
+        part = torch.zeros(nb, 2, Cp, device=DEV)
+        H.colstats_bf16(t, t.shape[0], Cp, part, nb)
+        return part, nb
+
+    # reference: one rank holding the whole batch
+    bn = make_bn()
+    part, nb = stats(y)
+    z_ref, sv = L.bn_fwd(y, part, nb, M, bn, relu=True)
+    dy_ref, _, dg_ref, db_ref = L.bn_bwd(dz, y, None, sv, bn.weight, relu=True)
+    torch.cuda.synchronize()
+
+    halves = [(y[: M // 2].contiguous(), dz[: M // 2].contiguous()), (y[M // 2:].contiguous(), dz[M // 2:].contiguous())]
+    rows = {}
+
+    def recorder(key):
+        def f(t):
+            rows[key] = t.clone()
+        return f
+
+    def adder(key):
+        def f(t):
+            t.add_(rows[key])
+        return f
+    try:
+        L.SYNC_BN_WORLD = 2
+        bns = [make_bn(), make_bn()]
+        for r, (yh, _) in enumerate(halves):                       # record the forward rows (local sums)
+            L.SYNC_BN_REDUCE = recorder(("f", r))
+            L.bn_fwd(yh, *stats(yh), M // 2, make_bn(), relu=True)
+        fwd = []
+        for r, (yh, _) in enumerate(halves):                       # forward with the other rank's row added
+            L.SYNC_BN_REDUCE = adder(("f", 1 - r))
+            fwd.append(L.bn_fwd(yh, *stats(yh), M // 2, bns[r], relu=True))
+        for r, (yh, dh) in enumerate(halves):                      # record the backward rows (they use the global mean / rstd)
+            L.SYNC_BN_REDUCE = recorder(("b", r))
+            L.bn_bwd(dh, yh, None, fwd[r][1], bns[r].weight, relu=True)
+        bwd = []
+        for r, (yh, dh) in enumerate(halves):
+            L.SYNC_BN_REDUCE = adder(("b", 1 - r))
+            bwd.append(L.bn_bwd(dh, yh, None, fwd[r][1], bns[r].weight, relu=True))
+        torch.cuda.synchronize()
+    finally:
+        L.SYNC_BN_REDUCE, L.SYNC_BN_WORLD = None, 1
+    z = torch.cat([fwd[0][0], fwd[1][0]])
+    dy = torch.cat([bwd[0][0], bwd[1][0]])
+    assert fwd[0][1].count == M and torch.allclose(fwd[0][1].mean, sv.mean, atol=1e-5) and torch.allclose(fwd[1][1].rstd, sv.rstd, rtol=1e-5)
+    assert (z.float() - z_ref.float()).abs().max().item() <= 2.0 ** -7 * z_ref.float().abs().max().item()
+    assert (dy.float() - dy_ref.float()).abs().max().item() <= 2.0 ** -7 * dy_ref.float().abs().max().item()
+    assert torch.allclose(bwd[0][2] + bwd[1][2], dg_ref, rtol=1e-4, atol=1e-3)      # per-rank sums add up to the global ones
+    assert torch.allclose(bwd[0][3] + bwd[1][3], db_ref, rtol=1e-4, atol=1e-3)
+    for r in range(2):                                             # every rank tracks the global running statistics
+        assert torch.allclose(bns[r].running_mean, bn.running_mean, atol=1e-5)
+        assert torch.allclose(bns[r].running_var, bn.running_var, rtol=1e-4)
+    # and the statistics really differ from per-rank ones
+    local = L.bn_fwd(halves[0][0], *stats(halves[0][0]), M // 2, make_bn(), relu=True)[1]
+    assert (local.mean - sv.mean).abs().max().item() > 0.1

@@ -437,7 +437,23 @@ def test_data_parallel_machinery_single_rank():
             # gradient (float atomics in the audio statistics perturb dV in the last bits and the trunk amplifies
             # that, DESIGN.md "Numerics"; tools/probe/dp_dbg.py); a mis-ordered pack gives O(1) errors or zeros.
             assert err <= 0.12 * max(p.grad.abs().max().item(), 1e-2 * gmax), f"{n}: {err}"
+        # SyncBN option: every BatchNorm layer all-reduces its statistics rows through RCCL (identity with one rank)
+        from peppa_amd import layers as PL
+        from peppa_amd.dist import enable_sync_bn
+        enable_sync_bn(True)
+        assert PL.SYNC_BN_REDUCE is not None and PL.SYNC_BN_WORLD == 1
+        net.zero_grad(set_to_none=True)
+        loss_sync = net.training_step(batch, 0)
+        loss_sync.backward()
+        torch.cuda.synchronize()
+        # (the all-reduced row is an fp32 sum where the local path accumulates partial rows in fp64: means differ in the
+        # last bits, and this tiny train-mode-BatchNorm net amplifies that; the arithmetic itself is checked to 1e-5 in
+        # test_kernels_gpu.py::test_sync_bn_two_ranks_in_one_process_match_the_global_batch)
+        assert abs(loss_sync.item() - loss.item()) <= 3e-3
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
     finally:
+        from peppa_amd.dist import enable_sync_bn
+        enable_sync_bn(False)
         os.environ["PEPPA_FORCE_DIST"] = "0"
         dist.destroy_process_group()
 
