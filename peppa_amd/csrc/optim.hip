@@ -6,6 +6,13 @@
 
 namespace {
 
+// Both kernels stream with 16-byte accesses where the tensor allows it (every pointer 16-byte aligned; chunk offsets are
+// multiples of 65536 elements): four times fewer memory instructions and four times the bytes in flight per thread than
+// the scalar loop, which left the 4-GB pass at 3.4 TB/s.
+__device__ __forceinline__ bool aligned16(const void* a, const void* b, const void* c, const void* d) {
+  return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const pp_tensor_list tl, const int* __restrict__ chunk_tensor,
                                                     const long long* __restrict__ chunk_off, int chunk, float* norms) {
   __shared__ float red[4];
@@ -15,7 +22,17 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const pp_tensor_list tl, con
   const float* g = tl.g[t];
   const long long end = off + chunk < n ? off + chunk : n;
   float s = 0.f;
-  for (long long i = off + threadIdx.x; i < end; i += 256) { const float v = g[i]; s += v * v; }
+  long long done = off;
+  if (aligned16(g, g, g, g)) {
+    const long long nvec = (end - off) >> 2;
+    const float4* g4 = (const float4*)(g + off);
+    for (long long i = threadIdx.x; i < nvec; i += 256) {
+      const float4 v = g4[i];
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    done = off + (nvec << 2);
+  }
+  for (long long i = done + threadIdx.x; i < end; i += 256) { const float v = g[i]; s += v * v; }
   s = block_sum<4>(s, red);
   if (threadIdx.x == 0) atomicAdd(norms + t, s);
 }
@@ -38,16 +55,40 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const pp_tensor_list tl, 
     coef = coef < 1.f ? coef : 1.f;
   }
   const long long end = off + chunk < n ? off + chunk : n;
-  for (long long i = off + threadIdx.x; i < end; i += 256) {
-    const float gi = g[i] * coef;
-    const float mi = m[i] * b1 + (1.f - b1) * gi;
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+  auto one = [&](const float gr, float& mi, float& vi, float& pi) __attribute__((always_inline)) {
+    const float gi = gr * coef;
+    mi = mi * b1 + (1.f - b1) * gi;
+    vi = vi * b2 + (1.f - b2) * gi * gi;
     float upd = mi / (sqrtf(vi) + eps);
-    const float pi = p[i];
     if (wd > 0.f) upd += wd * pi;
+    pi = pi - lr * upd;
+  };
+  long long done = off;
+  if (aligned16(p, g, m, v)) {
+    const long long nvec = (end - off) >> 2;
+    float4* p4 = (float4*)(p + off);
+    const float4* g4 = (const float4*)(g + off);
+    float4* m4 = (float4*)(m + off);
+    float4* v4 = (float4*)(v + off);
+    for (long long i = threadIdx.x; i < nvec; i += 256) {
+      const float4 gg = g4[i];
+      float4 mm = m4[i], vv = v4[i], pp = p4[i];
+      one(gg.x, mm.x, vv.x, pp.x);
+      one(gg.y, mm.y, vv.y, pp.y);
+      one(gg.z, mm.z, vv.z, pp.z);
+      one(gg.w, mm.w, vv.w, pp.w);
+      m4[i] = mm;
+      v4[i] = vv;
+      p4[i] = pp;
+    }
+    done = off + (nvec << 2);
+  }
+  for (long long i = done + threadIdx.x; i < end; i += 256) {
+    float mi = m[i], vi = v[i], pi = p[i];
+    one(g[i], mi, vi, pi);
     m[i] = mi;
     v[i] = vi;
-    p[i] = pi - lr * upd;
+    p[i] = pi;
   }
 }
 
