@@ -39,8 +39,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bfraw* __restrict__ x
     const int ch = lane + 64 * c;
     if (ch < nch) {
       float o[8];
+      const float4 g0 = *(const float4*)(gamma + ch * 8), g1 = *(const float4*)(gamma + ch * 8 + 4);
+      const float4 b0 = *(const float4*)(beta + ch * 8), b1 = *(const float4*)(beta + ch * 8 + 4);
+      const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) o[q] = (f[c][q] - mu) * rs * gamma[ch * 8 + q] + beta[ch * 8 + q];
+      for (int q = 0; q < 8; ++q) o[q] = (f[c][q] - mu) * rs * gm[q] + bt[q];
       *(uint4*)(y + (long long)row * D + ch * 8) = pack8(o);
     }
   }
@@ -62,21 +66,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bfraw* __restrict__ d
     for (int q = 0; q < 8; ++q) ag[c][q] = ab[c][q] = 0.f;
   const int r0 = wid * rows_per_wave;
   const int r1 = min(rows, r0 + rows_per_wave);
+  float gam[LN_MAXC][8];                     // this lane's gamma, once for all its rows
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + 64 * c;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) gam[c][q] = ch < nch ? gamma[ch * 8 + q] : 0.f;
+  }
+  // the next row's operands are requested before this row's two wave reductions (a row is one dependent chain)
+  uint4 nd[LN_MAXC], nx[LN_MAXC];
+  auto fetch = [&](const int row) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch && row < r1) {
+        nd[c] = *(const uint4*)(dy + (long long)row * D + ch * 8);
+        nx[c] = *(const uint4*)(x + (long long)row * D + ch * 8);
+      }
+    }
+  };
+  fetch(r0);
   for (int row = r0; row < r1; ++row) {
     const float mu = mean[row], rs = rstd[row];
     float g[LN_MAXC][8], xh[LN_MAXC][8];
     float s1 = 0.f, s2 = 0.f;
+    uint4 cd[LN_MAXC], cx[LN_MAXC];
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) { cd[c] = nd[c]; cx[c] = nx[c]; }
+    fetch(row + 1);
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nch) {
         float d[8], xx[8];
-        unpack8(*(const uint4*)(dy + (long long)row * D + ch * 8), d);
-        unpack8(*(const uint4*)(x + (long long)row * D + ch * 8), xx);
+        unpack8(cd[c], d);
+        unpack8(cx[c], xx);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           xh[c][q] = (xx[q] - mu) * rs;
-          g[c][q] = d[q] * gamma[ch * 8 + q];
+          g[c][q] = d[q] * gam[c][q];
           s1 += g[c][q];
           s2 += g[c][q] * xh[c][q];
           ag[c][q] += d[q] * xh[c][q];
