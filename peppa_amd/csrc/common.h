@@ -54,13 +54,24 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) through Abramowitz & Stegun 7.1.26 (erfc(|u|) = poly(t) e^{-u^2}, absolute error
+// <= 1.5e-7: two orders below the bf16 rounding of anything it feeds) from e = exp(-u^2), which the GELU derivative needs
+// anyway as its Gaussian factor: one v_exp, one v_rcp and a handful of FMAs instead of libm's erff, in kernels that are
+// VALU-bound on it (the wav2vec2 conv0 passes, the GELU epilogues).  The lower tail is formed without cancellation.
+__device__ __forceinline__ float gauss_cdf_from_exp(float u, float e) {
+  const float t = __frcp_rn(1.0f + 0.3275911f * fabsf(u));
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float h = 0.5f * poly * e;                      // = 0.5 erfc(|u|)
+  return u < 0.f ? h : 1.0f - h;
+}
 __device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  const float u = x * 0.70710678118654752f;
+  return x * gauss_cdf_from_exp(u, __expf(-u * u));
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const float u = x * 0.70710678118654752f;
+  const float e = __expf(-u * u);                       // = exp(-x^2 / 2)
+  return gauss_cdf_from_exp(u, e) + x * 0.3989422804014327f * e;
 }
 
 // ---- counter-based dropout mask (pp_dropout_*, the GEMM epilogue, pp_gelu_bwd_dropout) ------------------------------
