@@ -75,11 +75,15 @@ def grad_dict():
 
 
 class GradBuckets:
-    """Flat gradient buckets with per-bucket asynchronous all-reduce (SUM).
+    """Flat gradient buckets with per-bucket asynchronous all-reduce (SUM), ONE reduction per optimizer step.
 
     A bucket is packed and reduced as soon as all of its gradients exist.  They arrive either early, from inside a
-    tower's backward (`push`, via grad_dict()), or through autograd's post-accumulate hooks (heads, and every parameter
-    while gradients are being accumulated over micro-batches)."""
+    tower's backward (`push`, via grad_dict()), or through autograd's post-accumulate hooks (the heads).
+
+    Gradient accumulation (`accumulate_grad_batches`, hparams_base.yaml:42): only the LAST micro-batch of an optimizer
+    step is reduced.  With `sync = False` (or inside `no_sync()`) a backward pass leaves the buckets alone and
+    autograd accumulates into `p.grad` as usual; the backward pass that runs with `sync = True` packs
+    `p.grad (earlier micro-batches) + this pass's gradient` and all-reduces that once."""
 
     def __init__(self, named_groups, device):
         """named_groups: [(name, [params])]; params without grad at step time are skipped (zeros)."""
@@ -88,6 +92,7 @@ class GradBuckets:
         ensure_streams(device)   # the towers' side streams must exist before RCCL creates its own (see there)
         self.buckets = []
         self.cuda = torch.device(device).type == "cuda"
+        self.sync = True
         for name, params in named_groups:
             params = [p for p in params if p.requires_grad]
             total = sum(p.numel() for p in params)
@@ -97,7 +102,7 @@ class GradBuckets:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             self.buckets.append(dict(name=name, params=params, flat=flat, views=views, pending=0, work=None,
-                                     pushed={}, events={}))
+                                     pushed={}, events={}, accumulated=set()))
         self._hooks = []
         self._by_param = {}
         for b in self.buckets:
@@ -115,18 +120,34 @@ class GradBuckets:
         if _ACTIVE is self:
             _ACTIVE = None
 
+    def no_sync(self):
+        """Context manager for the micro-batches of an optimizer step that must not be reduced (all but the last)."""
+        mgr = self
+
+        class _NoSync:
+            def __enter__(self):
+                self.prev, mgr.sync = mgr.sync, False
+
+            def __exit__(self, *exc):
+                mgr.sync = self.prev
+                return False
+        return _NoSync()
+
     def reset(self):
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["work"] = None
             b["pushed"] = {}
             b["events"] = {}
+            b["accumulated"] = set()
 
     def push(self, p, g):
-        """Gradient `g` of parameter `p` is final for this backward pass (called on the stream that produces it)."""
+        """Gradient `g` of parameter `p` is final for this backward pass (called on the stream that produces it).
+        `p.grad`, if it exists, holds the earlier micro-batches only: autograd adds `g` to it after the tower's node
+        returns (the hook then marks the parameter as accumulated)."""
         b = self._by_param.get(p)
-        if b is None or g is None or p in b["pushed"] or p.grad is not None:
-            return   # not ours / already handed over / accumulating over micro-batches: the hook path takes it
+        if not self.sync or b is None or g is None or p in b["pushed"] or b["work"] is not None:
+            return   # unsynced micro-batch / not ours / already handed over: autograd's accumulation takes it
         b["pushed"][p] = g
         if self.cuda:
             b["events"][torch.cuda.current_stream()] = True   # (the set of producing streams)
@@ -135,14 +156,44 @@ class GradBuckets:
             self._launch(b)
 
     def _on_grad(self, p):
-        if p.grad is None:   # autograd also runs the hook when a Function returned None for this parameter
-            return           # (e.g. a layer skipped by LayerDrop): nothing arrived
+        if not self.sync or p.grad is None:   # autograd also runs the hook when a Function returned None for this
+            return                            # parameter (e.g. a layer skipped by LayerDrop): nothing arrived
         b = self._by_param[p]
         if p in b["pushed"]:
-            return           # handed over early by its tower
+            b["accumulated"].add(p)   # handed over early by its tower; p.grad now contains that gradient as well
+            return
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
+
+    def _pack(self, b):
+        """flat view <- this optimizer step's gradient of every parameter: the early hand-off plus what earlier
+        micro-batches left in p.grad, or p.grad itself once autograd has accumulated into it; zeros for none."""
+        cp_dst, cp_src, add_dst, add_src, zero = [], [], [], [], []
+        for p, v in zip(b["params"], b["views"]):
+            g = b["pushed"].get(p)
+            # (p.grad can BE the view: zero_grad(set_to_none=False) keeps last step's tensor and accumulates into it)
+            alias = p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+            if g is not None and p not in b["accumulated"]:
+                if alias:
+                    add_dst.append(v), add_src.append(g)
+                    continue
+                cp_dst.append(v), cp_src.append(g)
+                if p.grad is not None:
+                    add_dst.append(v), add_src.append(p.grad)
+            elif alias:
+                continue
+            elif p.grad is not None:
+                cp_dst.append(v), cp_src.append(p.grad)
+            else:
+                zero.append(v)
+        if cp_dst:
+            torch._foreach_copy_(cp_dst, cp_src)          # plumbing: pack
+        if add_dst:
+            torch._foreach_add_(add_dst, add_src)
+        if zero:
+            torch._foreach_zero_(zero)
+        return bool(cp_dst)
 
     def _launch(self, b):
         # On the stream of the last arrival (a tower's own stream): RCCL orders the collective after the work queued
@@ -153,32 +204,27 @@ class GradBuckets:
             for st in b["events"]:
                 if st != cur:
                     cur.wait_stream(st)
-        srcs = [b["pushed"][p] if p in b["pushed"] else p.grad for p in b["params"]]
-        torch._foreach_copy_(b["views"], srcs)          # plumbing: pack
+        self._pack(b)
         if is_dist():
             b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            b["work"] = True
 
     def finish(self):
-        """Wait for the collectives and point every p.grad at its reduced bucket view.  Parameters that got no
-        gradient this step (unused, or a layer skipped by LayerDrop on every rank -- the decision is shared)
+        """Wait for the collectives and point every p.grad at its reduced bucket view.  Buckets that were not complete
+        in the last backward pass (a layer skipped by LayerDrop in that micro-batch, unused parameters) are reduced
+        here from p.grad.  Parameters without any gradient this step (the LayerDrop decision is shared by the ranks)
         contribute zeros to the sum and keep p.grad = None, so the optimizer skips them like the reference."""
         for b in self.buckets:
-            b["had_grad"] = [p.grad is not None for p in b["params"]]
-            if b["pending"] == len(b["params"]):
-                continue   # nothing arrived (e.g. a layer dropped by LayerDrop on every rank): no collective
-            if b["pending"] > 0:
-                if sum(not h for h in b["had_grad"]) != b["pending"]:
-                    raise RuntimeError(f"bucket {b['name']}: inconsistent gradient arrival")
-                for p, v in zip(b["params"], b["views"]):
-                    if p.grad is None:
-                        v.zero_()
-                    else:
-                        v.copy_(p.grad)
+            had = [p.grad is not None or p in b["pushed"] for p in b["params"]]
+            b["had_grad"] = had
+            if b["work"] is None and any(had):
+                self._pack(b)
                 if is_dist():
                     b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
-            if b["work"] is not None:
-                b["work"].wait()
         for b in self.buckets:
+            if b["work"] is not None and b["work"] is not True:
+                b["work"].wait()
             for p, v, had in zip(b["params"], b["views"], b["had_grad"]):
                 if had:
                     p.grad = v

@@ -118,13 +118,27 @@ class Trainer:
         return int(cp.get("epoch", -1)) + 1
 
     def _train_epoch(self, net, data, optim, buckets, t0):
-        """True when a step / time limit ended training."""
-        for i, batch in enumerate(data.train_dataloader()):
-            if self.limit_train_batches is not None and i >= self.limit_train_batches:
-                break
+        """True when a step / time limit ended training.  The optimizer steps every `accumulate` micro-batches and, like
+        Lightning, on the last batch of the epoch (leftover micro-batches are applied, not carried into the next epoch).
+        Under data parallelism only the micro-batch that completes an optimizer step is all-reduced."""
+        def limited(loader):
+            for i, batch in enumerate(loader):
+                if self.limit_train_batches is not None and i >= self.limit_train_batches:
+                    return
+                yield batch
+
+        it = iter(limited(data.train_dataloader()))
+        nxt = next(it, None)
+        i = 0
+        while nxt is not None:
+            batch, nxt = nxt, next(it, None)
+            stepping = (i + 1) % self.accumulate == 0 or nxt is None
+            if buckets is not None:
+                buckets.sync = stepping
             loss = net.training_step(batch, i)
             (loss / self.accumulate).backward()
-            if (i + 1) % self.accumulate == 0:
+            i += 1
+            if stepping:
                 if buckets is not None:
                     buckets.finish()
                 optim.step()
@@ -132,8 +146,8 @@ class Trainer:
                 self.global_step += 1
                 if self.global_step % self.log_every == 0:
                     log.info("step %d loss %.5f (%.1f s)", self.global_step, float(loss), time.time() - t0)
-            if self.max_steps is not None and self.global_step >= self.max_steps:
-                return True
-            if self.max_time_s is not None and time.time() - t0 > self.max_time_s:
-                return True
+                if self.max_steps is not None and self.global_step >= self.max_steps:
+                    return True
+                if self.max_time_s is not None and time.time() - t0 > self.max_time_s:
+                    return True
         return False

@@ -3,6 +3,7 @@ backward and the SUM-reduced gradient buckets reproduce the single-process globa
 of the reference loss (oracle)."""
 import os
 import socket
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -62,6 +63,113 @@ def test_gather_and_sum_buckets_match_global_batch(tmp_path):
     assert abs(loss.item() - got["loss"].item()) < 1e-6
     assert (enc_v.weight.grad - got["gv"]).abs().max() < 1e-6   # SUM over ranks == single-process gradient
     assert (enc_a.bias.grad - got["ga"]).abs().max() < 1e-6
+
+
+def _accum_worker(rank, world, port, out, accumulate, early):
+    """`accumulate` micro-batches per optimizer step (hparams_base.yaml:42 has 8): only the last one is reduced, and
+    it carries the sum.  `early`: the audio stand-in hands its gradients over itself in the synced pass (as the
+    towers do through dist.grad_dict()) while p.grad still holds the earlier micro-batches."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PEPPA_FORCE_DIST="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from peppa_amd.dist import gather_embeddings, GradBuckets, grad_dict
+    from oracle import model as O
+    torch.manual_seed(0)
+    B, D = 3, 16
+    enc_v, enc_a = torch.nn.Linear(8, D), torch.nn.Linear(6, D)
+    unused = torch.nn.Parameter(torch.zeros(4))                        # never gets a gradient (SURVEY 0.15)
+    g = torch.Generator().manual_seed(100)
+    xv = torch.randn(accumulate, world * B, 8, generator=g)
+    xa = torch.randn(accumulate, world * B, 6, generator=g)
+    buckets = GradBuckets([("a", list(enc_a.parameters())), ("v", list(enc_v.parameters()) + [unused])], "cpu")
+    for step in range(2):                                              # two optimizer steps: state resets in between
+        for p in list(enc_v.parameters()) + list(enc_a.parameters()):
+            p.grad = None
+        for k in range(accumulate):
+            last = k == accumulate - 1
+            buckets.sync = last
+            V = enc_v(xv[k, rank * B:(rank + 1) * B] + step)
+            A = enc_a(xa[k, rank * B:(rank + 1) * B])
+            loss = O.TripletLoss(0.2)(*gather_embeddings(V, A)) / accumulate
+            if early and last:
+                gd = grad_dict()
+                ga_w, ga_b = torch.autograd.grad(loss, [enc_a.weight, enc_a.bias], retain_graph=True)
+                gd[enc_a.weight], gd[enc_a.bias] = ga_w, ga_b
+                assert buckets.buckets[0]["work"] is not None
+            elif early:
+                gd = grad_dict()     # unsynced pass: the hand-off must be ignored, autograd accumulates
+                gd[enc_a.weight] = torch.full_like(enc_a.weight, 1e6)
+                assert buckets.buckets[0]["work"] is None and not buckets.buckets[0]["pushed"]
+            loss.backward()
+        buckets.finish()
+        assert unused.grad is None
+    if rank == 0:
+        torch.save({"gv": enc_v.weight.grad.clone(), "gvb": enc_v.bias.grad.clone(), "ga": enc_a.weight.grad.clone(),
+                    "gab": enc_a.bias.grad.clone()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("accumulate,early", [(2, False), (2, True), (4, True)])
+def test_gradient_accumulation_under_data_parallel_matches_single_process(tmp_path, accumulate, early):
+    """VERDICT r1 weak #2 / ADVICE high: micro-batches after the first were dropped.  World 2 (gloo) with
+    accumulate_grad_batches > 1 must give the single-process gradient of the accumulated global batches."""
+    from oracle import model as O
+    world, port, out = 2, _free_port(), str(tmp_path / "r0.pt")
+    mp.spawn(_accum_worker, args=(world, port, out, accumulate, early), nprocs=world, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    B, D = 3, 16
+    enc_v, enc_a = torch.nn.Linear(8, D), torch.nn.Linear(6, D)
+    g = torch.Generator().manual_seed(100)
+    xv = torch.randn(accumulate, world * B, 8, generator=g)
+    xa = torch.randn(accumulate, world * B, 6, generator=g)
+    for k in range(accumulate):
+        (O.TripletLoss(0.2)(enc_v(xv[k] + 1), enc_a(xa[k])) / accumulate).backward()
+    for name, p in (("gv", enc_v.weight), ("gvb", enc_v.bias), ("ga", enc_a.weight), ("gab", enc_a.bias)):
+        assert (p.grad - got[name]).abs().max() < 1e-6, name
+
+
+def test_trainer_accumulates_steps_on_epoch_end_and_syncs_once(monkeypatch):
+    """peppa_amd.trainer.Trainer: optimizer step every `accumulate` micro-batches AND on the last batch of the epoch
+    (Lightning's behaviour; leftovers must not leak into the next epoch); under data parallelism `sync` is raised for
+    exactly the micro-batch that completes a step."""
+    from peppa_amd import trainer as T
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(()))
+            self.config = {}
+
+        def training_step(self, batch, i):
+            return self.w * batch
+
+        def configure_optimizers(self):
+            return torch.optim.SGD(self.parameters(), lr=1.0)
+
+    class Data:
+        def train_dataloader(self):
+            return iter([1.0, 2.0, 3.0, 4.0, 5.0])
+
+    class Buckets:
+        def __init__(self):
+            self.sync, self.seen, self.finished = True, [], 0
+
+        def finish(self):
+            self.finished += 1
+
+    b = Buckets()
+    monkeypatch.setattr(T, "is_dist", lambda: True)
+    monkeypatch.setattr(T, "default_buckets", lambda net, dev: b)
+    net = Net()
+    orig = net.training_step
+    net.training_step = lambda batch, i: (b.seen.append(b.sync), orig(batch, i))[1]
+    tr = T.Trainer(accumulate_grad_batches=2, max_epochs=2)
+    tr.fit(net, Data())
+    assert b.seen == [False, True, False, True, True] * 2       # 5 batches: steps after 2, 4 and the leftover 5th
+    assert b.finished == 6 and tr.global_step == 6
+    assert abs(net.w.item() + 2 * 15.0 / 2) < 1e-6               # every micro-batch applied exactly once, / accumulate
+    assert net.w.grad is None
 
 
 def test_single_process_is_identity():
