@@ -279,6 +279,12 @@ int pp_triplet_loss_bwd(const float* V, const float* A, int N, int D, const floa
 int pp_cosine_matrix(const float* U, const float* V, int Nu, int Nv, int D, float* out, float* ws, pp_stream_t s);
 /* pig/loss.py:41-48 contrastive(M, margin) forward on a given similarity matrix; ws N*N+3N floats */
 int pp_contrastive_fwd(const float* S, int N, float margin, float* loss, float* ws, pp_stream_t s);
+/* Backward passes of the two (the reference's are plain differentiable torch expressions, pig/loss.py:41-55):
+ * dU [Nu][D], dV [Nv][D] from dS [Nu][Nv]; ws 2*(Nu+Nv)*D + Nu + Nv floats */
+int pp_cosine_matrix_bwd(const float* U, const float* V, int Nu, int Nv, int D, const float* dS, float* dU, float* dV,
+                         float* ws, pp_stream_t s);
+/* dS [N][N] = dloss[0] * d contrastive / dS (dloss read from device memory); ws 3*N + 1 floats */
+int pp_contrastive_bwd(const float* S, int N, float margin, const float* dloss, float* dS, float* ws, pp_stream_t s);
 /* pig/metrics.py:45-52 triplet_accuracy: a, p, n fp32 [M][D] -> out [M] ((sign(diff)+1)/2 or diff) */
 int pp_triplet_accuracy(const float* a, const float* p, const float* n, int M, int D, int discrete, float* out,
                         pp_stream_t s);

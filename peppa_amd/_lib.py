@@ -113,6 +113,8 @@ SIGNATURES = {
     "pp_recall_at_n": [P, I, I, I, P, I, I, P, I, P, P],
     "pp_cosine_matrix": [P, P, I, I, I, P, P, P],
     "pp_contrastive_fwd": [P, I, F, P, P, P],
+    "pp_cosine_matrix_bwd": [P, P, I, I, I, P, P, P, P, P],
+    "pp_contrastive_bwd": [P, I, F, P, P, P, P],
     "pp_triplet_accuracy": [P, P, P, I, I, I, P, P],
     "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P, P],
 }

@@ -11,9 +11,11 @@ dict: `save_hyperparameters(config)`, pig/models.py:228), `hparams_name` = "conf
 `optimizer_states`, `lr_schedulers`, `callbacks` (keyed by the callback CLASS) and `pytorch-lightning_version`.
 
 Lightning is not installed here, so
- * reading goes through a restricted unpickler: torch / numpy / collections resolve normally, a short list of harmless
-   builtins too, and every other global (Lightning's callback class used as a dict key, its enums ...) becomes an
-   inert stub that remembers its dotted name.  Nothing from the file is executed;
+ * reading goes through a restricted unpickler with an EXACT (module, name) allowlist (tensor / storage rebuilders,
+   dtypes, OrderedDict, numpy array reconstruction, a short list of harmless builtins); every other global --
+   Lightning's callback class used as a dict key, its enums, and equally `torch.utils.collect_env.run` or
+   `numpy.testing.*` in a hostile file -- becomes an inert stub that remembers its dotted name and only stores the
+   arguments it is "called" with.  No callable from the file is executed;
  * writing uses the real `ModelCheckpoint` class as the key when Lightning is importable and the dotted name otherwise;
    `callback_states` accepts both, so files written here load there and vice versa.
 """
@@ -30,7 +32,53 @@ import yaml
 MODEL_CHECKPOINT = "pytorch_lightning.callbacks.model_checkpoint.ModelCheckpoint"
 LIGHTNING_VERSION = "1.4.9"          # requirements.txt:59 of the reference
 
-_SAFE_ROOTS = ("torch", "numpy", "collections", "_codecs", "copyreg")
+def _allowed_globals():
+    """Exact (module, name) allowlist, the way torch._weights_only_unpickler does it: what a tensor / optimizer-state /
+    config pickle needs to rebuild itself, and nothing that takes a callable or a command.  A root-module allowlist
+    ("anything under torch.*") is NOT safe: torch.utils.collect_env.run, torch.hub.*, numpy.testing.* are one REDUCE
+    away from a shell."""
+    import collections
+    import copyreg
+    import _codecs
+    import numpy
+    import torch._utils as tu
+    ok = {
+        ("collections", "OrderedDict"): collections.OrderedDict,
+        ("_codecs", "encode"): _codecs.encode,
+        ("copyreg", "_reconstructor"): copyreg._reconstructor,     # object.__new__(cls) for classes resolved HERE
+        ("copyreg", "__newobj__"): copyreg.__newobj__,
+        ("numpy", "dtype"): numpy.dtype,
+        ("numpy", "ndarray"): numpy.ndarray,
+        ("torch", "Size"): torch.Size,
+        ("torch", "device"): torch.device,
+        ("torch", "Tensor"): torch.Tensor,
+        ("torch.nn.parameter", "Parameter"): torch.nn.Parameter,
+        ("torch.serialization", "_get_layout"): torch.serialization._get_layout,
+    }
+    for name in ("_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_parameter", "_rebuild_parameter_with_state",
+                 "_rebuild_device_tensor_from_numpy"):
+        if hasattr(tu, name):
+            ok[("torch._utils", name)] = getattr(tu, name)
+    try:
+        from numpy._core import multiarray as ma
+    except ImportError:  # numpy < 2
+        from numpy.core import multiarray as ma
+    for mod in ("numpy.core.multiarray", "numpy._core.multiarray"):
+        ok[(mod, "_reconstruct")] = ma._reconstruct
+        ok[(mod, "scalar")] = ma.scalar
+    for name, obj in vars(torch).items():
+        if isinstance(obj, torch.dtype):
+            ok[("torch", name)] = obj
+        elif name.endswith("Storage") and isinstance(obj, type):
+            ok[("torch", name)] = obj
+    for name in ("TypedStorage", "UntypedStorage"):
+        ok[("torch.storage", name)] = getattr(torch.storage, name)
+    return ok
+
+
+_ALLOWED = None
+_LIGHTNING_OK = {("pytorch_lightning.callbacks.model_checkpoint", "ModelCheckpoint"),
+                 ("pytorch_lightning.utilities.parsing", "AttributeDict")}
 _SAFE_BUILTINS = {"set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "str", "bytes", "bytearray",
                   "complex", "slice", "range", "object"}
 _STUBS = {}
@@ -64,12 +112,15 @@ def _stub(module, name):
 
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        root = module.split(".")[0]
-        if root in _SAFE_ROOTS:
+        global _ALLOWED
+        if _ALLOWED is None:
+            _ALLOWED = _allowed_globals()
+        hit = _ALLOWED.get((module, name))
+        if hit is not None:
+            return hit
+        if module in ("builtins", "__builtin__") and name in _SAFE_BUILTINS:   # (protocol 2 writes the py2 module name)
             return super().find_class(module, name)
-        if module == "builtins" and name in _SAFE_BUILTINS:
-            return super().find_class(module, name)
-        if root == "pytorch_lightning":
+        if (module, name) in _LIGHTNING_OK:
             try:
                 return super().find_class(module, name)
             except (ImportError, AttributeError):
@@ -167,13 +218,18 @@ def config_from(checkpoint, hparams_file=None):
 
 def load_model(cls, checkpoint_path, map_location=None, hparams_file=None, strict=True):
     """`PeppaPig.load_from_checkpoint` (pig/evaluation.py:52): rebuild from the stored config, then load the weights.
-    The stored config may say `audio.pretrained: true` (the checkpoint was trained from the fairseq weights); the
-    state_dict replaces every weight, so the architecture is built from random init and the config is kept as stored."""
+    The stored config may say `pretrained: true` (the run started from the fairseq / Kinetics weights); the
+    state_dict replaces every weight, so the architecture is built from random init, the video encoder keeps the
+    pretrained input normalisation, and the config is kept as stored."""
     cp = load_checkpoint(checkpoint_path, map_location="cpu")
     config = config_from(cp, hparams_file)
     build = copy.deepcopy(config)
     build.setdefault("audio", {})["pretrained"] = False
+    video_pretrained = bool(build.setdefault("video", {}).get("pretrained", False))
+    build["video"]["pretrained"] = False
     net = cls(build)
+    if video_pretrained and hasattr(net.video_encoder, "mark_pretrained"):
+        net.video_encoder.mark_pretrained()       # Kinetics / ImageNet input normalisation, as trained
     net.config = config
     missing, unexpected = net.load_state_dict(cp["state_dict"], strict=False)
     unexpected = [k for k in unexpected if not k.endswith("num_batches_tracked")]

@@ -21,15 +21,10 @@ struct SG {
   int ksplit;         // >1: atomicAdd partial results into zeroed C
 };
 
-__global__ __launch_bounds__(256) void sgemm_kernel(const SG p) {
-  __shared__ float As[32][17];
-  __shared__ float Bs[16][33];
+// one 32 x 32 tile of the product on the exact-fp32 matrix instruction; acc[r] = C(m0 + wm*16 + (lane>>4)*4 + r, n0 + wn*16 + (lane&15))
+__device__ __forceinline__ f32x4 sgemm_tile(const SG& p, int m0, int n0, int kb, int ke, float (*As)[17], float (*Bs)[33]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  const int kchunk = ((p.K + p.ksplit - 1) / p.ksplit + 15) & ~15;
-  const int kb = blockIdx.z * kchunk;
-  const int ke = min(p.K, kb + kchunk);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = kb; k0 < ke; k0 += 16) {
 #pragma unroll
@@ -55,13 +50,27 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const SG p) {
     }
     __syncthreads();
   }
+  return acc;
+}
+
+__device__ __forceinline__ void sgemm_body(const SG& p, int bz) {
+  __shared__ float As[32][17];
+  __shared__ float Bs[16][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  if (m0 >= p.M || n0 >= p.N) return;   // (pair launches: the grid covers the larger problem)
+  const int kchunk = ((p.K + p.ksplit - 1) / p.ksplit + 15) & ~15;
+  const int kb = bz * kchunk;
+  const int ke = min(p.K, kb + kchunk);
+  f32x4 acc = sgemm_tile(p, m0, n0, kb, ke, As, Bs);
   const int n = n0 + wn * 16 + (lane & 15);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = m0 + wm * 16 + (lane >> 4) * 4 + r;
     if (m < p.M && n < p.N) {
       float v = acc[r];
-      if (p.bias && blockIdx.z == 0) v += p.bias[n];
+      if (p.bias && bz == 0) v += p.bias[n];
       float* cp = p.C + m * p.sc_m + n * p.sc_n;
       if (p.ksplit > 1) { atomicAdd(cp, v); continue; }
       if (p.act == 1) v = tanhf(v);
@@ -71,6 +80,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const SG p) {
     }
   }
 }
+
+__global__ __launch_bounds__(256) void sgemm_kernel(const SG p) { sgemm_body(p, blockIdx.z); }
+// two independent products in one launch (blockIdx.z picks the problem; no split-K)
+__global__ __launch_bounds__(256) void sgemm_pair_kernel(const SG p0, const SG p1) { sgemm_body(blockIdx.z ? p1 : p0, 0); }
 
 int sgemm(hipStream_t s, const float* A, long long sa_m, long long sa_k, const float* B, long long sb_k, long long sb_n, float* C,
           long long sc_m, long long sc_n, int M, int N, int K, const float* bias = nullptr, int act = 0, const float* aux = nullptr,
@@ -283,17 +296,96 @@ __global__ void gdiag_kernel(float* G, const float* rowc, const float* colc, int
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) G[(long long)i * N + i] = -(rowc[i] + colc[i]) / ((float)N * (float)N);
 }
-// dX = dloss * (dXn - Xn*(Xn.dXn)) / ||X||   (cosine_matrix normalisation, no clamp: pig/loss.py:51-55)
-__global__ __launch_bounds__(256) void cosnorm_bwd_kernel(const float* __restrict__ dXn, const float* __restrict__ Xn,
-                                                          const float* __restrict__ nrm, const float* __restrict__ dloss,
-                                                          float* __restrict__ dX, int D) {
+// dX = dloss * (dXn' - Xn*(Xn.dXn')) / ||X||   (cosine_matrix normalisation, no clamp: pig/loss.py:51-55), both operands of
+// the loss in one launch (blockIdx.y: 0 = V side, 1 = A side).  The stored coefficient matrix G has a zero diagonal; the
+// diagonal term gd_r = -(rowc_r + colc_r) / N^2 (every hinge term pulls its diagonal entry down) is applied here:
+// dXn'_r = dXn_r + gd_r * Other_r.  dloss == nullptr: scale 1.
+struct CosBwd {
+  const float *dXn, *Xn, *nrm, *other;
+  float* dX;
+};
+__global__ __launch_bounds__(256) void cosnorm_bwd_kernel(const CosBwd p0, const CosBwd p1, const float* __restrict__ dloss,
+                                                          const float* __restrict__ rowc, const float* __restrict__ colc,
+                                                          float invn2, int rows0, int rows1, int D) {
+  __shared__ float red[4];
+  const CosBwd& p = blockIdx.y ? p1 : p0;
+  const long long r = blockIdx.x;
+  if (r >= (blockIdx.y ? rows1 : rows0)) return;
+  const float gd = rowc ? -(rowc[r] + colc[r]) * invn2 : 0.f;
+  float dot = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float g = p.dXn[r * D + d] + (rowc ? gd * p.other[r * D + d] : 0.f);
+    dot += p.Xn[r * D + d] * g;
+  }
+  dot = block_sum<4>(dot, red);
+  const float sc = (dloss ? dloss[0] : 1.f) / p.nrm[r];
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float g = p.dXn[r * D + d] + (rowc ? gd * p.other[r * D + d] : 0.f);
+    p.dX[r * D + d] = sc * (g - p.Xn[r * D + d] * dot);
+  }
+}
+
+// Launch 1 of the loss: row r of V and A -> unit rows, norms, the diagonal S_rr = Vn_r . An_r; zeroes the accumulators
+// of launch 2.  cosine_matrix divides by the norm WITHOUT a clamp (pig/loss.py:51-55): a zero row gives NaN, as there.
+__global__ __launch_bounds__(256) void loss_prep_kernel(const float* __restrict__ V, const float* __restrict__ A, const LossWs w,
+                                                        float* __restrict__ loss, int D) {
   __shared__ float red[4];
   const long long r = blockIdx.x;
-  float dot = 0.f;
-  for (int d = threadIdx.x; d < D; d += 256) dot += Xn[r * D + d] * dXn[r * D + d];
-  dot = block_sum<4>(dot, red);
-  const float sc = dloss[0] / nrm[r];
-  for (int d = threadIdx.x; d < D; d += 256) dX[r * D + d] = sc * (dXn[r * D + d] - Xn[r * D + d] * dot);
+  float sv = 0.f, sa = 0.f, va = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float x = V[r * D + d], y = A[r * D + d];
+    sv += x * x; sa += y * y; va += x * y;
+  }
+  sv = block_sum<4>(sv, red); sa = block_sum<4>(sa, red); va = block_sum<4>(va, red);
+  const float nv = sqrtf(sv), na = sqrtf(sa);
+  for (int d = threadIdx.x; d < D; d += 256) { w.Vn[r * D + d] = V[r * D + d] / nv; w.An[r * D + d] = A[r * D + d] / na; }
+  if (threadIdx.x == 0) {
+    w.vnorm[r] = nv; w.anorm[r] = na; w.rowc[r] = 0.f; w.colc[r] = 0.f;
+    w.diag[r] = va / (nv * na);
+    if (r == 0) loss[0] = 0.f;
+  }
+}
+// The hinges compare S_ij with the diagonal entries S_jj / S_ii, which belong to OTHER tiles of launch 2; they are
+// taken from launch 1's dot product Vn_r . An_r instead of torch.diag(S).  Same value up to the summation order
+// (~1e-7, inside the 1e-6 tolerance against the live reference's golden vectors; the loss is continuous in it).
+// Launch 2: one 32 x 32 tile of S per workgroup; epilogue = both hinges, G (zero diagonal), active counts, loss partial.
+__global__ __launch_bounds__(256) void loss_tile_kernel(const LossWs w, const float* __restrict__ diag, float* __restrict__ loss,
+                                                        int N, int D, float margin) {
+  __shared__ float As[32][17];
+  __shared__ float Bs[16][33];
+  __shared__ float red[4];
+  const SG p{w.Vn, D, 1, w.An, 1, D, nullptr, 0, 0, N, N, D, nullptr, nullptr, 0, 0, 1};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const f32x4 acc = sgemm_tile(p, m0, n0, 0, D, As, Bs);
+  const float inv = 1.f / ((float)N * (float)N);
+  const int n = n0 + wn * 16 + (lane & 15);
+  const float dn = n < N ? diag[n] : 0.f;
+  float part = 0.f, cc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + wm * 16 + (lane >> 4) * 4 + r;
+    float g = 0.f, rc = 0.f;
+    if (m < N && n < N && m != n) {
+      const float hc = margin + acc[r] - dn;         // column direction: against S_nn
+      const float hr = margin + acc[r] - diag[m];    // row direction: against S_mm
+      if (hc > 0.f) { part += hc; g += inv; cc += 1.f; }
+      if (hr > 0.f) { part += hr; g += inv; rc += 1.f; }
+    }
+    if (m < N && n < N) w.G[(long long)m * N + n] = g;
+    // row m's active count: the 16 lanes that share (lane >> 4)
+    rc += __shfl_xor(rc, 1); rc += __shfl_xor(rc, 2); rc += __shfl_xor(rc, 4); rc += __shfl_xor(rc, 8);
+    if ((lane & 15) == 0 && m < N && rc != 0.f) atomicAdd(w.rowc + m, rc);
+  }
+  cc += __shfl_xor(cc, 16); cc += __shfl_xor(cc, 32);   // column n: the four lane groups
+  if (lane < 16 && n < N && cc != 0.f) atomicAdd(w.colc + n, cc);
+  part = block_sum<4>(part, red);
+  if (threadIdx.x == 0 && part != 0.f) atomicAdd(loss, part * inv);
+}
+__global__ void scale_f32_kernel(float* x, const float* sc, long long n) {
+  const float k = sc[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= k;
 }
 
 }  // namespace
@@ -385,13 +477,16 @@ extern "C" int pp_triplet_loss_fwd(const float* V, const float* A, int N, int D,
   PP_CHECK_ARG(N > 0 && D > 0 && V && A && loss && ws, "pp_triplet_loss_fwd: bad arguments");
   PP_CHECK_ARG(ws_bytes >= pp_triplet_workspace_bytes(N, D), "pp_triplet_loss_fwd: workspace too small");
   const LossWs w = loss_ws(ws, N, D);
-  // cosine_matrix: U / ||U|| without clamp (eps = 0), pig/loss.py:51-55
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(N), dim3(256), 0, S_, V, w.Vn, w.vnorm, D, 0.f);
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(N), dim3(256), 0, S_, A, w.An, w.anorm, D, 0.f);
-  RC(sgemm(S_, w.Vn, D, 1, w.An, 1, D, w.G, N, 1, N, N, D));  // S = Vn An^T
-  hipLaunchKernelGGL(diag_kernel, dim3((N + 255) / 256), dim3(256), 0, S_, w.G, w.diag, w.rowc, w.colc, loss, N);
-  hipLaunchKernelGGL(hinge_kernel, dim3(N), dim3(256), 0, S_, w.G, w.diag, w.rowc, w.colc, loss, N, margin);
-  hipLaunchKernelGGL(gdiag_kernel, dim3((N + 255) / 256), dim3(256), 0, S_, w.G, w.rowc, w.colc, N);
+  // two launches (the N = world x B global loss sits between the embedding all-gather and the backward pass)
+  hipLaunchKernelGGL(loss_prep_kernel, dim3(N), dim3(256), 0, S_, V, A, w, loss, D);
+  hipLaunchKernelGGL(loss_tile_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, S_, w, (const float*)w.diag, loss, N, D, margin);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+static int launch_pair(hipStream_t s, const SG& p0, const SG& p1) {
+  const int M = p0.M > p1.M ? p0.M : p1.M, N = p0.N > p1.N ? p0.N : p1.N;
+  hipLaunchKernelGGL(sgemm_pair_kernel, dim3((N + 31) / 32, (M + 31) / 32, 2), dim3(256), 0, s, p0, p1);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -400,10 +495,12 @@ extern "C" int pp_triplet_loss_bwd(const float* V, const float* A, int N, int D,
                                    float* dV, float* dA, pp_stream_t s) {
   PP_CHECK_ARG(N > 0 && D > 0 && V && A && dloss && ws && dV && dA, "pp_triplet_loss_bwd: bad arguments");
   const LossWs w = loss_ws((void*)ws, N, D);
-  RC(sgemm(S_, w.G, N, 1, w.An, D, 1, w.dVn, D, 1, N, D, N));   // dVn = G An
-  RC(sgemm(S_, w.G, 1, N, w.Vn, D, 1, w.dAn, D, 1, N, D, N));   // dAn = G^T Vn
-  hipLaunchKernelGGL(cosnorm_bwd_kernel, dim3(N), dim3(256), 0, S_, w.dVn, w.Vn, w.vnorm, dloss, dV, D);
-  hipLaunchKernelGGL(cosnorm_bwd_kernel, dim3(N), dim3(256), 0, S_, w.dAn, w.An, w.anorm, dloss, dA, D);
+  const SG gv{w.G, N, 1, w.An, D, 1, w.dVn, D, 1, N, D, N, nullptr, nullptr, 0, 0, 1};   // dVn = G An   (off-diagonal part)
+  const SG ga{w.G, 1, N, w.Vn, D, 1, w.dAn, D, 1, N, D, N, nullptr, nullptr, 0, 0, 1};   // dAn = G^T Vn
+  RC(launch_pair(S_, gv, ga));
+  const CosBwd cv{w.dVn, w.Vn, w.vnorm, w.An, dV}, ca{w.dAn, w.An, w.anorm, w.Vn, dA};
+  hipLaunchKernelGGL(cosnorm_bwd_kernel, dim3(N, 2), dim3(256), 0, S_, cv, ca, dloss, (const float*)w.rowc, (const float*)w.colc,
+                     1.f / ((float)N * (float)N), N, N, D);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -509,6 +606,47 @@ extern "C" int pp_contrastive_fwd(const float* S, int N, float margin, float* lo
   hipLaunchKernelGGL(copy_f32_kernel, dim3((N * N + 255) / 256), dim3(256), 0, S_, S, G, (long long)N * N);
   hipLaunchKernelGGL(diag_kernel, dim3((N + 255) / 256), dim3(256), 0, S_, G, diag, rowc, colc, loss, N);
   hipLaunchKernelGGL(hinge_kernel, dim3(N), dim3(256), 0, S_, G, diag, rowc, colc, loss, N, margin);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// Backward of cosine_matrix (the reference's is an ordinary differentiable torch expression, pig/loss.py:51-55):
+// dU = J_norm(U)^T (dS Vn), dV = J_norm(V)^T (dS^T Un).  ws: 2 (Nu + Nv) D + Nu + Nv floats.
+extern "C" int pp_cosine_matrix_bwd(const float* U, const float* Vv, int Nu, int Nv, int D, const float* dS, float* dU,
+                                    float* dV, float* ws, pp_stream_t s) {
+  PP_CHECK_ARG(Nu > 0 && Nv > 0 && D > 0 && U && Vv && dS && dU && dV && ws, "pp_cosine_matrix_bwd: bad arguments");
+  float* Un = ws;
+  float* Vn = Un + (size_t)Nu * D;
+  float* dUn = Vn + (size_t)Nv * D;
+  float* dVn = dUn + (size_t)Nu * D;
+  float* un = dVn + (size_t)Nv * D;
+  float* vn = un + Nu;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(Nu), dim3(256), 0, S_, U, Un, un, D, 0.f);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(Nv), dim3(256), 0, S_, Vv, Vn, vn, D, 0.f);
+  const SG gu{dS, Nv, 1, Vn, D, 1, dUn, D, 1, Nu, D, Nv, nullptr, nullptr, 0, 0, 1};   // dUn = dS Vn
+  const SG gv{dS, 1, Nv, Un, D, 1, dVn, D, 1, Nv, D, Nu, nullptr, nullptr, 0, 0, 1};   // dVn = dS^T Un
+  RC(launch_pair(S_, gu, gv));
+  const CosBwd cu{dUn, Un, un, nullptr, dU}, cv{dVn, Vn, vn, nullptr, dV};
+  hipLaunchKernelGGL(cosnorm_bwd_kernel, dim3(Nu > Nv ? Nu : Nv, 2), dim3(256), 0, S_, cu, cv, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, 0.f, Nu, Nv, D);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// Backward of contrastive(M, margin) (pig/loss.py:41-48): dM = dloss * G, G_ij = ([hinge_c > 0] + [hinge_r > 0]) / N^2 off
+// the diagonal and minus the number of active terms of row i and column i over N^2 on it.  ws: 3 N + 1 floats.
+extern "C" int pp_contrastive_bwd(const float* S, int N, float margin, const float* dloss, float* dS, float* ws,
+                                  pp_stream_t s) {
+  PP_CHECK_ARG(N > 0 && S && dloss && dS && ws, "pp_contrastive_bwd: bad arguments");
+  float* diag = ws;
+  float* rowc = diag + N;
+  float* colc = rowc + N;
+  float* scratch = colc + N;
+  hipLaunchKernelGGL(copy_f32_kernel, dim3((N * N + 255) / 256), dim3(256), 0, S_, S, dS, (long long)N * N);
+  hipLaunchKernelGGL(diag_kernel, dim3((N + 255) / 256), dim3(256), 0, S_, dS, diag, rowc, colc, scratch, N);
+  hipLaunchKernelGGL(hinge_kernel, dim3(N), dim3(256), 0, S_, dS, diag, rowc, colc, scratch, N, margin);
+  hipLaunchKernelGGL(gdiag_kernel, dim3((N + 255) / 256), dim3(256), 0, S_, dS, rowc, colc, N);
+  hipLaunchKernelGGL(scale_f32_kernel, dim3((N * N + 255) / 256), dim3(256), 0, S_, dS, dloss, (long long)N * N);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

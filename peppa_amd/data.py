@@ -8,12 +8,21 @@ from .util import pad_audio_batch, pad_video_batch
 
 @dataclass
 class Clip:
+    """Video clip with associated audio (pig/data.py:28-37): the durations are SECONDS (`clip.duration` /
+    `clip.audio.duration` of the moviepy clip, pig/data.py:72-73), not frame or sample counts."""
     video: torch.Tensor
     audio: torch.Tensor
-    duration: float = None
+    video_duration: float = None
+    audio_duration: float = None
     filename: str = None
     offset: float = None
     index: int = None
+
+    @property
+    def duration(self):
+        """`pig.triplet.triplets` groups clips by `x.duration` (pig/triplet.py:110); the validation path matches by
+        audio duration (pig/models.py:288, pig/triplet.py:44)."""
+        return self.audio_duration
 
 
 @dataclass
@@ -29,11 +38,11 @@ class ClipBatch:
 
 
 def collate(data):
-    """Zero-pad clips to the longest in the batch along time (video) / samples (audio)."""
-    video, audio = zip(*[(x.video, x.audio) for x in data])
+    """pig/data.py:60-65: zero-pad clips to the longest in the batch along time (video) / samples (audio); the batch
+    durations are the clips' durations in seconds (validation matches triplets on `audio_duration`)."""
+    video, audio, vlen, alen = zip(*[(x.video, x.audio, x.video_duration, x.audio_duration) for x in data])
     return ClipBatch(video=pad_video_batch(video), audio=pad_audio_batch(audio),
-                     video_duration=torch.tensor([x.video.shape[1] for x in data]),
-                     audio_duration=torch.tensor([x.audio.shape[1] for x in data]))
+                     video_duration=torch.tensor(vlen), audio_duration=torch.tensor(alen))
 
 
 @dataclass
@@ -63,14 +72,18 @@ def _ragged_table(tensors, lengths, device, align=16):
     return buf, table.to(device, non_blocking=True)
 
 
-def collate_device(clips, device="cuda", video_dtype=torch.float32):
+def collate_device(clips, device="cuda", video_dtype=torch.float32, fps=10, audio_sample_rate=44100):
     """`collate` (pig/data.py:60-65) for RawClips, on the GPU: one byte per sample crosses PCIe, the /255 scaling,
     (T,H,W,C)->(C,T,H,W) transpose, zero-padding and stacking run in HIP kernels (csrc/collate.hip).
 
     video_dtype=torch.float32: `ClipBatch.video` is the reference's fp32 (B,3,Tmax,H,W) batch in [0,1], bit-identical
     to featurize + pad_video_batch.  video_dtype=torch.uint8: it stays a padded uint8 (B,Tmax,H,W,3) batch, which
     `encode_video` accepts directly (the stem's input kernel scales and normalises it) -- 4x less HBM traffic and no
-    fp32 copy; the embeddings are bit-identical to the fp32 route."""
+    fp32 copy; the embeddings are bit-identical to the fp32 route.
+
+    Batch durations are SECONDS like the reference's (pig/data.py:64-65, 72-73); a RawClip without them gets
+    frames / `fps` and samples / `audio_sample_rate` (10 fps snippets, pig/preprocess.py:45-47; 44.1 kHz,
+    pig/data.py:26)."""
     from . import hip as H
     if len(clips) == 0:
         raise ValueError("collate_device: empty batch")
@@ -105,8 +118,8 @@ def collate_device(clips, device="cuda", video_dtype=torch.float32):
         t.record_stream(torch.cuda.current_stream(dev))
     dur = lambda xs, fallback: torch.tensor([f if x is None else x for x, f in zip(xs, fallback)])
     return ClipBatch(video=video, audio=audio,
-                     video_duration=dur([c.video_duration for c in clips], T),
-                     audio_duration=dur([c.audio_duration for c in clips], Ls))
+                     video_duration=dur([c.video_duration for c in clips], [t / fps for t in T]),
+                     audio_duration=dur([c.audio_duration for c in clips], [l / audio_sample_rate for l in Ls]))
 
 
 def synthetic_batch(batch, frames, size, samples, seed=1234, device="cpu"):
@@ -114,5 +127,38 @@ def synthetic_batch(batch, frames, size, samples, seed=1234, device="cpu"):
     g = torch.Generator(device="cpu").manual_seed(seed)
     video = torch.rand(batch, 3, frames, size, size, generator=g)
     audio = 0.1 * torch.randn(batch, 1, samples, generator=g)
-    dur = torch.full((batch,), float(samples))
-    return ClipBatch(video.to(device), audio.to(device), torch.full((batch,), float(frames)), dur)
+    # seconds, as in the reference's batches: 10 fps video snippets, 16 kHz synthetic audio
+    return ClipBatch(video.to(device), audio.to(device), torch.full((batch,), frames / 10.0),
+                     torch.full((batch,), samples / 16000.0))
+
+
+def synthetic_structured_batch(batch, frames, size, samples, seed=4321, device="cpu"):
+    """Synthetic clips that differ from each other the way real clips do (a colour cast, smooth spatio-temporal
+    texture, a moving blob; audio = a few amplitude-modulated tones): iid-noise clips (`synthetic_batch`) are
+    statistically identical, so a random-init model maps them all to almost the same embedding and any ranking of
+    them (triplet accuracy, recall) is decided by rounding noise.  Same value ranges as `synthetic_batch`."""
+    import math
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)
+    n = lambda *s: torch.randn(*s, generator=g)
+    base = 0.2 + 0.6 * r(batch, 3, 1, 1, 1)
+    coarse = n(batch, 3, max(2, frames // 4 + 1), 7, 7)
+    tex = F.interpolate(coarse, size=(frames, size, size), mode="trilinear", align_corners=True)
+    contrast = 0.1 + 0.3 * r(batch, 1, 1, 1, 1)
+    tt = torch.linspace(0, 1, frames).view(1, frames, 1, 1)
+    yy = torch.linspace(0, 1, size).view(1, 1, size, 1)
+    xx = torch.linspace(0, 1, size).view(1, 1, 1, size)
+    p0, vel = r(batch, 2, 1, 1, 1), 0.6 * (r(batch, 2, 1, 1, 1) - 0.5)
+    rad = 0.05 + 0.15 * r(batch, 1, 1, 1)
+    blob = torch.exp(-((yy - (p0[:, 0] + vel[:, 0] * tt)) ** 2 + (xx - (p0[:, 1] + vel[:, 1] * tt)) ** 2) / (2 * rad ** 2))
+    colour = r(batch, 3, 1, 1, 1) - 0.5
+    video = (base + contrast * tex + colour * blob.unsqueeze(1) + 0.02 * n(batch, 3, frames, size, size)).clamp_(0, 1)
+    t = torch.arange(samples).view(1, 1, samples) / 16000.0
+    freq = 100.0 * torch.exp(math.log(40.0) * r(batch, 3, 1))            # 100 Hz .. 4 kHz
+    mod = 0.5 + 0.5 * torch.sin(2 * math.pi * (0.5 + 4 * r(batch, 3, 1)) * t + 6.28 * r(batch, 3, 1))
+    amp = 0.02 + 0.08 * r(batch, 3, 1)
+    audio = (amp * mod * torch.sin(2 * math.pi * freq * t + 6.28 * r(batch, 3, 1))).sum(dim=1, keepdim=True)
+    audio = audio + 0.01 * n(batch, 1, samples)
+    return ClipBatch(video.to(device), audio.float().to(device), torch.full((batch,), frames / 10.0),
+                     torch.full((batch,), samples / 16000.0))

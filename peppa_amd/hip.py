@@ -437,6 +437,18 @@ def contrastive_fwd(S, margin, loss):
     call("pp_contrastive_fwd", _p(S, f32), N, margin, _p(loss, f32), _p(ws, f32), _s())
 
 
+def cosine_matrix_bwd(U, V, dS, dU, dV):
+    Nu, Nv, D = U.shape[0], V.shape[0], U.shape[1]
+    ws = torch.empty(2 * (Nu + Nv) * D + Nu + Nv, dtype=f32, device=U.device)
+    call("pp_cosine_matrix_bwd", _p(U, f32), _p(V, f32), Nu, Nv, D, _p(dS, f32), _p(dU, f32), _p(dV, f32), _p(ws, f32), _s())
+
+
+def contrastive_bwd(S, margin, dloss, dS):
+    N = S.shape[0]
+    ws = torch.empty(3 * N + 1, dtype=f32, device=S.device)
+    call("pp_contrastive_bwd", _p(S, f32), N, margin, _p(dloss, f32), _p(dS, f32), _p(ws, f32), _s())
+
+
 def triplet_accuracy(a, p, n, discrete, out):
     call("pp_triplet_accuracy", _p(a, f32), _p(p, f32), _p(n, f32), a.shape[0], a.shape[1], int(discrete), _p(out, f32), _s())
 

@@ -38,22 +38,55 @@ class TripletLoss(torch.nn.Module):
         return TripletLossFn.apply(V, A, self.margin)
 
 
+class CosineMatrixFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, V):
+        if not (U.is_cuda and V.is_cuda):
+            raise H.PeppaHipError("peppa_amd.loss needs CUDA/HIP tensors (no CPU fallback)")
+        U, V = U.contiguous().float(), V.contiguous().float()
+        out = torch.empty(U.shape[0], V.shape[0], dtype=f32, device=U.device)
+        H.cosine_matrix(U, V, out)
+        ctx.save_for_backward(U, V)
+        return out
+
+    @staticmethod
+    def backward(ctx, dS):
+        U, V = ctx.saved_tensors
+        dU, dV = torch.empty_like(U), torch.empty_like(V)
+        H.cosine_matrix_bwd(U, V, dS.contiguous().float(), dU, dV)
+        return dU, dV
+
+
+class ContrastiveFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, M, margin):
+        if not M.is_cuda:
+            raise H.PeppaHipError("peppa_amd.loss needs CUDA/HIP tensors (no CPU fallback)")
+        if M.dim() != 2 or M.shape[0] != M.shape[1]:
+            raise ValueError(f"contrastive: square similarity matrix expected, got {tuple(M.shape)}")
+        M = M.contiguous().float()
+        loss = torch.empty(1, dtype=f32, device=M.device)
+        H.contrastive_fwd(M, float(margin), loss)
+        ctx.save_for_backward(M)
+        ctx.margin = float(margin)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (M,) = ctx.saved_tensors
+        dM = torch.empty_like(M)
+        H.contrastive_bwd(M, ctx.margin, dloss.reshape(1).contiguous().float(), dM)
+        return dM, None
+
+
 def cosine_matrix(U, V):
-    "Matrix of cosine similarities between the rows of U and the rows of V (no gradient)."
-    U, V = U.detach().contiguous().float(), V.detach().contiguous().float()
-    out = torch.empty(U.shape[0], V.shape[0], dtype=f32, device=U.device)
-    H.cosine_matrix(U, V, out)
-    return out
+    "Returns the matrix of cosine similarity between each row of U and each row of V (differentiable, pig/loss.py:51-55)."
+    return CosineMatrixFn.apply(U, V)
 
 
 def contrastive(M, margin=0.2):
-    "Contrastive margin loss over a similarity matrix M (forward value only)."
-    if M.requires_grad:
-        raise NotImplementedError("contrastive(M) on a pre-computed matrix has no backward on the HIP path; "
-                                  "use TripletLoss(margin)(V, A)")
-    loss = torch.empty(1, dtype=f32, device=M.device)
-    H.contrastive_fwd(M.contiguous().float(), float(margin), loss)
-    return loss.reshape(())
+    "Returns contrastive margin loss over similarity matrix M (differentiable, pig/loss.py:41-48)."
+    return ContrastiveFn.apply(M, margin)
 
 
 class MILNCELoss(torch.nn.Module):

@@ -17,6 +17,7 @@ from . import optimization as opt
 from .data import ClipBatch
 from .dist import gather_embeddings, grad_dict
 from .triplet import TripletBatch as EmbeddingTripletBatch, score_triplets
+from .targeted_triplets import TripletBatch
 from .transforms import SwapCT  # noqa: F401  (API surface)
 
 try:  # the reference subclasses LightningModule; Lightning is optional here
@@ -27,11 +28,7 @@ except Exception:  # pragma: no cover - Lightning absent in this image
     _Base = nn.Module
 
 
-class TargetedTripletBatch:
-    """Shape contract of pig/targeted_triplets.py:28-33 (anchor audio, positive/negative video)."""
-
-    def __init__(self, anchor, positive, negative):
-        self.anchor, self.positive, self.negative = anchor, positive, negative
+TargetedTripletBatch = TripletBatch     # the class `forward` dispatches on (pig/models.py:20,238)
 
 
 class AttnPoolFn(torch.autograd.Function):
@@ -166,10 +163,10 @@ class LastStep(nn.Module):
 
 class Wav2VecEncoder(nn.Module):
     def __init__(self, path, pretrained=True, freeze_feature_extractor=False, freeze_encoder_layers=None,
-                 pooling='average', project=True, full=False):
+                 pooling='average', project=True, full=False, weights=None):
         super().__init__()
         if pretrained:
-            self.audio = _load_fairseq_checkpoint(path)
+            self.audio = _load_fairseq_checkpoint(path, weights)
         else:
             self.audio = A.wav2vec2_base(num_out=28)
         if freeze_feature_extractor:
@@ -202,10 +199,37 @@ class Wav2VecEncoder(nn.Module):
         return _project_normalize(self.audiopool(features), self.project)
 
 
-def _load_fairseq_checkpoint(path):
-    raise RuntimeError(f"audio.pretrained=true needs the fairseq checkpoint {path!r} and fairseq itself "
-                       "(pig/models.py:70-72); neither is available offline. Use pretrained: false or load a "
-                       "state_dict with torchaudio parameter names.")
+def _load_weights_file(path):
+    """A state_dict file (tensors only) through the restricted unpickler of peppa_amd.checkpoint."""
+    from .checkpoint import load_checkpoint
+    sd = load_checkpoint(path)
+    return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+
+
+def _load_fairseq_checkpoint(path, weights=None):
+    """pig/models.py:70-72 imports the fairseq checkpoint `path` through fairseq + torchaudio's import_fairseq_model;
+    neither package exists offline.  `weights` (yaml: `mi355x: {audio_weights: file}`) is the same model already
+    converted: a state_dict with torchaudio parameter names (what `import_fairseq_model(...).state_dict()` saves)."""
+    if weights is None:
+        raise RuntimeError(f"audio.pretrained=true needs the fairseq checkpoint {path!r} and fairseq itself "
+                           "(pig/models.py:70-72); neither is available offline. Use pretrained: false (run.py "
+                           "--random_init), or give `mi355x: {audio_weights: <state_dict with torchaudio names>}`.")
+    audio = A.wav2vec2_base(num_out=28)
+    audio.load_state_dict(_load_weights_file(weights))
+    return audio
+
+
+def _pretrained_trunk(trunk, kind, weights):
+    """`pretrained=True` downloads Kinetics / ImageNet weights in the reference (pig/models.py:123-127,164).  Offline
+    that is impossible, and silently training from random init while the config (and every checkpoint's
+    hyper_parameters) says `pretrained: true` is worse than failing: require the weights as a local state_dict with
+    torchvision parameter names (yaml: `mi355x: {video_weights: file}`)."""
+    if weights is None:
+        raise RuntimeError(f"video.pretrained=true needs the {kind} weights torchvision would download; they cannot be "
+                           "fetched offline. Use pretrained: false (run.py --random_init), or give "
+                           "`mi355x: {video_weights: <state_dict with torchvision names>}`.")
+    trunk.load_state_dict(_load_weights_file(weights))
+    return trunk
 
 
 def _video_trunk_launch(enc, x, save):
@@ -278,15 +302,14 @@ class VideoTrunkFn(torch.autograd.Function):
 
 
 class R3DEncoder(nn.Module):
-    def __init__(self, pretrained=True, project=True, version='r3d_18', pooling='average'):
+    def __init__(self, pretrained=True, project=True, version='r3d_18', pooling='average', weights=None):
         super().__init__()
         self.pretrained = pretrained
         if version not in ('r3d_18', 'mc3_18', 'r2plus1d_18'):
             raise ValueError(f"Invalid version {version}")
-        if pretrained:
-            logging.warning("video.pretrained=true: Kinetics weights cannot be downloaded offline; using random "
-                            "init with the kinetics normalisation constants (load a state_dict to override)")
         self.video = V.VideoResNet(version)
+        if pretrained:
+            _pretrained_trunk(self.video, "Kinetics", weights)
         self.project = nn.Linear(512, 512) if project else nn.Identity()
         if pooling == 'attention':
             self.videopool = VideoAttention(512, 128)
@@ -295,6 +318,12 @@ class R3DEncoder(nn.Module):
         else:
             raise ValueError(f"Invalid pooling {pooling}")
         self.norm_kind = "kinetics" if self.pretrained else "peppa"
+        self.transform = build_transform(self.norm_kind)
+
+    def mark_pretrained(self):
+        """The weights come from a checkpoint of a `pretrained: true` run (checkpoint.load_model): built from random
+        init, then overwritten; the input normalisation is the pretrained one (pig/models.py:140)."""
+        self.pretrained, self.norm_kind = True, "kinetics"
         self.transform = build_transform(self.norm_kind)
 
     def forward(self, x):
@@ -307,13 +336,12 @@ class R3DEncoder(nn.Module):
 class ImageEncoder(nn.Module):
     """Static (per-frame) encoder of hparams_static.yaml: resnet18 trunk on every frame, pooled over time."""
 
-    def __init__(self, pretrained=True, project=True, pooling='average'):
+    def __init__(self, pretrained=True, project=True, pooling='average', weights=None):
         super().__init__()
         self.pretrained = pretrained
-        if pretrained:
-            logging.warning("video.pretrained=true: ImageNet weights cannot be downloaded offline; using random "
-                            "init with the imagenet normalisation constants (load a state_dict to override)")
         self.image = V.ResNet18()
+        if pretrained:
+            _pretrained_trunk(self.image, "ImageNet", weights)
         for param in self.image.fc.parameters():
             param.requires_grad = False
         self.project = nn.Linear(512, 512) if project else nn.Identity()
@@ -329,6 +357,10 @@ class ImageEncoder(nn.Module):
     @property
     def video(self):   # VideoTrunkFn reads `.video` (the trunk) and `.norm_kind`
         return self.image
+
+    def mark_pretrained(self):
+        self.pretrained, self.norm_kind = True, "imagenet"
+        self.transform = build_transform(self.norm_kind)
 
     def forward(self, x):
         feats = VideoTrunkFn.apply(x, self, torch.is_grad_enabled(), *self.image.trunk_parameters())
@@ -367,11 +399,12 @@ class PeppaPig(_Base):
         self.loss = TripletLoss(margin=self.config['margin'])
         static = self.config['video'].get('static', False)
         video_config = {key: value for key, value in self.config['video'].items() if key != 'static'}
+        extra = config.get('mi355x', {}) or {}     # optional block the reference ignores: local pretrained weights
         if static:
-            self.video_encoder = ImageEncoder(**video_config)
+            self.video_encoder = ImageEncoder(**video_config, weights=extra.get('video_weights'))
         else:
-            self.video_encoder = R3DEncoder(**video_config)
-        self.audio_encoder = Wav2VecEncoder(**config['audio'])
+            self.video_encoder = R3DEncoder(**video_config, weights=extra.get('video_weights'))
+        self.audio_encoder = Wav2VecEncoder(**config['audio'], weights=extra.get('audio_weights'))
         self._logged = {}
         # optional `mi355x:` block (ignored by the reference): run the two encoders on separate HIP streams
         self._overlap = bool(config.get('mi355x', {}).get('overlap_encoders', True))

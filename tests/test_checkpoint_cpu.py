@@ -119,6 +119,49 @@ def test_unpickler_does_not_run_foreign_globals(tmp_path):
     assert isinstance(cp["x"], C._Stub) and C.dotted_name(type(cp["x"])) in ("posix.system", "os.system", "nt.system")
 
 
+@pytest.mark.parametrize("payload", ["torch_collect_env", "numpy_testing", "torch_load_bytes", "torch_hub"])
+def test_unpickler_does_not_run_torch_or_numpy_rooted_callables(tmp_path, payload):
+    """a root-module allowlist let `torch.utils.collect_env.run("...")` through.  The allowlist
+    is exact now: a torch.* / numpy.* callable that is not a tensor rebuilder becomes a stub and never runs."""
+    marker = tmp_path / "marker"
+    cmd = f"touch {marker}"
+
+    class Evil:
+        def __reduce__(self):
+            if payload == "torch_collect_env":
+                import torch.utils.collect_env as ce
+                return (ce.run, (cmd,))
+            if payload == "numpy_testing":
+                import numpy.testing._private.utils as u
+                return (u.runstring, (f"import os; os.system({cmd!r})", {}))
+            if payload == "torch_load_bytes":
+                return (torch.storage._load_from_bytes, (b"not a pickle",))
+            return (torch.hub.load, ("/nonexistent", "x"))
+    path = str(tmp_path / "evil.ckpt")
+    torch.save({"state_dict": {"w": torch.ones(2)}, "x": Evil()}, path)
+    cp = C.load_checkpoint(path)
+    assert not marker.exists()
+    assert isinstance(cp["x"], C._Stub)
+    assert torch.equal(cp["state_dict"]["w"], torch.ones(2))   # ordinary tensors still load
+
+
+def test_unpickler_allowlist_covers_what_checkpoints_contain(tmp_path):
+    import collections
+    import numpy as np
+    cp = {"state_dict": collections.OrderedDict(a=torch.arange(6, dtype=torch.bfloat16).view(2, 3), b=torch.nn.Parameter(torch.ones(2)),
+                                                 c=torch.tensor(3, dtype=torch.int64), d=torch.zeros(2, dtype=torch.float16)),
+          "np": np.arange(4, dtype=np.float32), "npscalar": np.float64(2.5), "size": torch.Size([2, 3]), "dtype": torch.float32,
+          "dev": torch.device("cpu"), "set": {1, 2}, "nested": [(1, 2.0, "s", b"b", None, True)]}
+    path = str(tmp_path / "plain.ckpt")
+    torch.save(cp, path)
+    got = C.load_checkpoint(path)
+    assert torch.equal(got["state_dict"]["a"], cp["state_dict"]["a"]) and got["state_dict"]["a"].dtype == torch.bfloat16
+    assert isinstance(got["state_dict"]["b"], torch.nn.Parameter)
+    assert (got["np"] == cp["np"]).all() and got["npscalar"] == 2.5 and got["size"] == cp["size"]
+    assert got["dtype"] is torch.float32 and got["dev"] == torch.device("cpu") and got["set"] == {1, 2}
+    assert got["nested"] == cp["nested"]
+
+
 def test_model_checkpoint_callback_and_load_best_model(tmp_path):
     root = tmp_path / "version_0"
     cb = C.ModelCheckpoint(monitor="valnarr_triplet", mode="max", save_last=True, save_top_k=1,

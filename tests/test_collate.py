@@ -98,7 +98,9 @@ def test_collate_device_matches_reference_golden():
         batch = collate_device(clips, "cuda")
         assert np.array_equal(batch.video.cpu().numpy(), d[f"{tag}_video_batch"])
         assert np.array_equal(batch.audio.cpu().numpy(), d[f"{tag}_audio_batch"])
-        assert batch.video_duration.tolist() == d[f"{tag}_T"].tolist()          # defaults: frame / sample counts
+        # clips without durations: seconds at the reference's 10 fps / 44.1 kHz (pig/preprocess.py:45-47, pig/data.py:26)
+        assert batch.video_duration.tolist() == pytest.approx([t / 10 for t in d[f"{tag}_T"].tolist()])
+        assert batch.audio_duration.tolist() == pytest.approx([a.shape[1] / 44100 for a in audio])
 
 
 @pytest.mark.gpu

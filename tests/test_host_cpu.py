@@ -136,6 +136,13 @@ def test_triplet_pairing_and_geometry():
     g = ConvGeom(2, (8, 28, 28), 64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1))
     assert g.out_thw == (8, 14, 14) and g.out_cstride == 240 and cpad(921) == 928
     from peppa_amd.data import Clip, collate
-    b = collate([Clip(torch.zeros(3, 4, 8, 8), torch.zeros(1, 100)), Clip(torch.zeros(3, 6, 8, 8), torch.zeros(1, 80))])
+    # the reference's Clip fields (pig/data.py:28-37, built by featurize :72-76); durations are SECONDS
+    clips = [Clip(video=torch.zeros(3, 4, 8, 8), audio=torch.zeros(1, 100), video_duration=0.4, audio_duration=0.41,
+                  filename="a.avi"),
+             Clip(torch.zeros(3, 6, 8, 8), torch.zeros(1, 80), 0.6, 0.59, "b.avi", offset=1.5, index=3)]
+    b = collate(clips)
     assert b.video.shape == (2, 3, 6, 8, 8) and b.audio.shape == (2, 1, 100)
-    assert b.video_duration.tolist() == [4, 6] and b.audio_duration.tolist() == [100, 80]
+    assert torch.equal(b.video_duration, torch.tensor([0.4, 0.6])) and torch.equal(b.audio_duration, torch.tensor([0.41, 0.59]))
+    assert clips[1].duration == 0.59 and clips[1].filename == "b.avi"
+    trip = list(T.triplets([Clip(torch.zeros(1), torch.ones(1), 1.0, 2.0, "x"), Clip(torch.zeros(1), torch.ones(1), 1.1, 2.0, "y")]))
+    assert len(trip) == 1 and isinstance(trip[0], T.Triplet)

@@ -460,6 +460,79 @@ def test_triplet_loss_golden(golden_dir):
     np.testing.assert_allclose(dV2.numpy(), 8.0 * d["dV_64"], atol=2e-6)
 
 
+@pytest.mark.parametrize("N", [1, 5, 33, 64, 100, 512])
+def test_triplet_loss_ragged_sizes_against_oracle(N):
+    """The two-launch loss (prep + 32x32 hinge tiles) at sizes that do not fill its tiles, against the oracle's closed
+    form (pinned to the live reference by tests/golden/ref_loss.npz); N = 1 has no off-diagonal term: loss 0, no NaN."""
+    from oracle import model as O
+    import pig.loss
+    g = torch.Generator().manual_seed(N)
+    V = (torch.randn(N, 96, generator=g) * 3).requires_grad_()
+    A = (torch.randn(N, 96, generator=g) + 0.3 * V.detach()).requires_grad_()
+    ref = O.TripletLoss(0.2)(V, A)
+    ref.backward()
+    Vd, Ad = V.detach().to(DEV).requires_grad_(), A.detach().to(DEV).requires_grad_()
+    loss = pig.loss.TripletLoss(0.2)(Vd, Ad)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    assert (Vd.grad.cpu() - V.grad).abs().max() < 3e-7 and (Ad.grad.cpu() - A.grad).abs().max() < 3e-7
+
+
+def test_cosine_matrix_and_contrastive_are_differentiable(golden_dir):
+    """pig/loss.py:41-55: both are ordinary differentiable torch expressions in the reference.  Values against the live
+    reference's golden vectors, gradients against the oracle's autograd, composed == TripletLoss."""
+    from oracle import model as O
+    import pig.loss
+    d = np.load(os.path.join(golden_dir, "ref_loss.npz"))
+    for n in (4, 64):
+        V, A = torch.tensor(d[f"V_{n}"]), torch.tensor(d[f"A_{n}"])
+        Vd, Ad = V.to(DEV).requires_grad_(), A.to(DEV).requires_grad_()
+        loss = pig.loss.contrastive(pig.loss.cosine_matrix(Vd, Ad), margin=0.2)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(loss.item() - float(d[f"loss_{n}"])) < 1e-6
+        np.testing.assert_allclose(Vd.grad.cpu().numpy(), d[f"dV_{n}"], atol=3e-7)
+        np.testing.assert_allclose(Ad.grad.cpu().numpy(), d[f"dA_{n}"], atol=3e-7)
+    # rectangular cosine_matrix with an arbitrary upstream gradient; un-normalised rows
+    g = torch.Generator().manual_seed(3)
+    U, W, R = torch.randn(37, 50, generator=g) * 2, torch.randn(21, 50, generator=g), torch.randn(37, 21, generator=g)
+    Ur, Wr = U.clone().requires_grad_(), W.clone().requires_grad_()
+    (O.cosine_matrix(Ur, Wr) * R).sum().backward()
+    Ud, Wd = U.to(DEV).requires_grad_(), W.to(DEV).requires_grad_()
+    S = pig.loss.cosine_matrix(Ud, Wd)
+    (S * R.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    close(S.detach(), O.cosine_matrix(U, W), rtol=1e-5, atol=1e-6, name="cosine_matrix")
+    close(Ud.grad, Ur.grad, rtol=1e-4, atol=1e-6, name="cosine_matrix dU")
+    close(Wd.grad, Wr.grad, rtol=1e-4, atol=1e-6, name="cosine_matrix dV")
+    # contrastive on a given matrix, scaled upstream gradient
+    M = (torch.randn(19, 19, generator=g) * 0.3)
+    Mr = M.clone().requires_grad_()
+    (3.0 * O.contrastive(Mr, 0.35)).backward()
+    Md = M.to(DEV).requires_grad_()
+    out = pig.loss.contrastive(Md, margin=0.35)
+    (3.0 * out).backward()
+    torch.cuda.synchronize()
+    assert abs(out.item() - O.contrastive(M, 0.35).item()) < 1e-6
+    close(Md.grad, Mr.grad, rtol=1e-5, atol=1e-7, name="contrastive dM")
+    assert not pig.loss.cosine_matrix(Ud.detach(), Wd.detach()).requires_grad
+
+
+def test_triplet_accuracy_golden_with_exact_tie(golden_dir):
+    """pig/metrics.py:45-52 through pp_triplet_accuracy on the live reference's fixture (incl. an exact tie -> 0.5)."""
+    import pig.metrics
+    d = np.load(os.path.join(golden_dir, "ref_metrics.npz"))
+    anc, pos, neg = (torch.tensor(d[k]).to(DEV) for k in ("anchor", "positive", "negative"))
+    acc = pig.metrics.triplet_accuracy(anc, pos, neg)
+    diff = pig.metrics.triplet_accuracy(anc, pos, neg, discrete=False)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(acc.cpu().numpy(), d["acc"])
+    assert acc[5].item() == 0.5
+    np.testing.assert_allclose(diff.cpu().numpy(), d["diff"], atol=2e-7)
+    assert diff[5].item() == 0.0
+
+
 def test_bertadam_golden(golden_dir):
     d = np.load(os.path.join(golden_dir, "ref_bertadam.npz"))
     ps = [torch.tensor(d[f"p0_{i}"]).to(DEV) for i in range(5)]

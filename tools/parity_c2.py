@@ -10,6 +10,7 @@ import copy
 import os
 import sys
 import time
+import types
 import warnings
 
 warnings.filterwarnings("ignore")
@@ -44,6 +45,7 @@ def main():
     ap.add_argument("--version", default="r2plus1d_18")
     ap.add_argument("--no-bwd", action="store_true")
     ap.add_argument("--no-autocast", action="store_true")
+    ap.add_argument("--blocks", action="store_true", help="teacher-forced forward/backward of every residual block at this shape")
     ap.add_argument("--threads", type=int, default=16)
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
@@ -73,27 +75,44 @@ def main():
     loss32 = ref.loss(V32, A32)
     print(f"oracle forward {time.time() - t0:.1f} s; loss {loss32.item():.6f}", flush=True)
     acts32 = dict(acts)
+    acts16 = grads16 = None
+    if not args.no_autocast:   # torch's own bf16 autocast of the oracle: the yardstick for "what bf16 operands cost"
+        ref2 = O.PeppaPigOracle(cfg, dropout=0.0, layer_drop=0.0).train()   # (a second instance: the fp32 graph of `ref`
+        ref2.load_state_dict(sd)                                             # is still needed for its backward pass)
+        h2 = [getattr(ref2.video_encoder.video, s).register_forward_hook(
+            lambda m, i, o, s=s: acts.__setitem__(s, o.detach().float())) for s in stages]
+        t0 = time.time()
+        gR2 = torch.Generator().manual_seed(77)
+        Rv2 = torch.randn(B, 512, generator=gR2)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            V16g = ref2.encode_video(batch.video)
+        V16 = V16g.detach().float()
+        acts16 = dict(acts)
+        grads16 = None
+        if not args.no_bwd:
+            (V16g.float() * Rv2).sum().backward()
+            grads16 = {n: p.grad for n, p in ref2.named_parameters() if p.grad is not None}
+        del ref2
+        print(f"oracle bf16-autocast forward+backward {time.time() - t0:.1f} s", flush=True)
+    # gradients are compared under a SMOOTH objective <V, Rv> + <A, Ra> with fixed random Rv, Ra: the hinge loss of
+    # near-identical random-init embeddings is a difference of almost cancelling terms, so its gradient amplifies the
+    # forward rounding of V / A by ~30x and says nothing about the backward kernels (measured: 100 % "error")
+    gR = torch.Generator().manual_seed(77)
+    Rv, Ra = torch.randn(B, 512, generator=gR), torch.randn(B, 512, generator=gR)
     if not args.no_bwd:
         t0 = time.time()
-        loss32.backward()
+        ((V32 * Rv).sum() + (A32 * Ra).sum()).backward()
         print(f"oracle backward {time.time() - t0:.1f} s", flush=True)
-    acts16 = None
-    if not args.no_autocast:
-        ref2 = copy.deepcopy(ref)
-        ref2.load_state_dict(sd)
-        rv2 = ref2.video_encoder.video
-        acts.clear()
-        h2 = [getattr(rv2, s).register_forward_hook(lambda m, i, o, s=s: acts.__setitem__(s, o.detach().float())) for s in stages]
-        t0 = time.time()
-        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
-            V16 = ref2.encode_video(batch.video).float()
-        acts16 = dict(acts)
-        print(f"oracle bf16-autocast forward {time.time() - t0:.1f} s", flush=True)
+    ref_grads = {n: p.grad.detach().clone() for n, p in ref.named_parameters() if p.grad is not None}
     for h in hooks:
         h.remove()
 
-    # HIP, stage by stage (free running)
     gb = batch.to("cuda")
+    if args.blocks:
+        bn_state = copy.deepcopy(hv.state_dict())
+        blocks_teacher_forced(rv, hv, acts32["stem"], B)
+        hv.load_state_dict(bn_state)
+    # HIP, stage by stage (free running)
     with torch.no_grad():
         x = gb.video
         cur = torch.empty(x.numel() // 3, 8, dtype=torch.bfloat16, device="cuda")
@@ -112,9 +131,12 @@ def main():
             print(f"{s:8s} {rel(from_cl(cur, B, thw, C), acts32[s]):12.5f} {y16}")
         hv.load_state_dict(bn_state)   # undo the running-statistics update of this diagnostic pass
     net.zero_grad(set_to_none=True)
-    loss = net.training_step(gb, 0)
+    with torch.no_grad():
+        loss = net.training_step(gb, 0)
+    hv.load_state_dict(bn_state)
     if not args.no_bwd:
-        loss.backward()
+        Vg, Ag = net.encode_pair(gb.video, gb.audio)
+        ((Vg * Rv.cuda()).sum() + (Ag * Ra.cuda()).sum()).backward()
     torch.cuda.synchronize()
     hv.load_state_dict(bn_state)
     with torch.no_grad():
@@ -130,22 +152,63 @@ def main():
     print(f"audio  emb: min cos {ca.min().item():.6f} max-abs {(Ah - A32d).abs().max().item():.5f}")
     print(f"loss: HIP {loss.item():.6f} oracle {loss32.item():.6f} |d| {abs(loss.item() - loss32.item()):.6f}")
     if not args.no_bwd:
-        refp = dict(ref.named_parameters())
         by_stage = {}
+        gmax = max(g.norm().item() for g in ref_grads.values())
         for n, p in net.named_parameters():
-            pr = refp[n]
-            if pr.grad is None or p.grad is None:
+            if n not in ref_grads or p.grad is None:
                 continue
+            pr = types.SimpleNamespace(grad=ref_grads[n])
             parts = n.split(".")
             key = ".".join(parts[:3]) if parts[0] == "video_encoder" and parts[1] == "video" else \
                 (".".join(parts[:2]) if parts[0] == "video_encoder" else "audio")
-            d = by_stage.setdefault(key, [0.0, 0.0, 0.0])
+            d = by_stage.setdefault(key, [0.0, 0.0, 0.0, 0.0])
             d[0] += (p.grad.detach().cpu() - pr.grad).pow(2).sum().item()
             d[1] += pr.grad.pow(2).sum().item()
-            d[2] = max(d[2], rel(p.grad, pr.grad))
-        print("gradient rel-L2 per stage (all tensors pooled / worst tensor):")
-        for k, (e, r, w) in by_stage.items():
-            print(f"  {k:32s} {(e / (r + 1e-30)) ** 0.5:9.4f} {w:9.4f}")
+            if grads16 is not None and n in grads16:
+                d[3] += (grads16[n].float() - pr.grad).pow(2).sum().item()
+            if pr.grad.norm().item() > 1e-4 * gmax:     # (tensors whose true gradient is ~0, e.g. k_proj.bias: skip)
+                d[2] = max(d[2], rel(p.grad, pr.grad))
+        print("gradient rel-L2 per stage under <V,Rv> + <A,Ra> (all tensors pooled / worst tensor / torch bf16 autocast pooled):")
+        for k, (e, r, w, e16) in by_stage.items():
+            print(f"  {k:32s} {(e / (r + 1e-30)) ** 0.5:9.4f} {w:9.4f} {(e16 / (r + 1e-30)) ** 0.5:9.4f}")
+
+
+def to_cl(x, cp):
+    B, C = x.shape[:2]
+    y = x.permute(0, 2, 3, 4, 1).reshape(-1, C)
+    out = torch.zeros(y.shape[0], cp)
+    out[:, :C] = y
+    return out.to(torch.bfloat16).cuda()
+
+
+def blocks_teacher_forced(rv, hv, x0, B):
+    """Every residual block (and the stem's second unit chain via the layers' inputs) with the ORACLE's activation as
+    input and a fixed random output gradient: isolates the kernels chosen at this geometry from the depth effect."""
+    rb = lambda t: t.to(torch.bfloat16).float()
+    g = torch.Generator().manual_seed(5)
+    x = x0
+    print(f"{'block':10s} {'fwd':>8s} {'dx':>8s} {'worst dW':>9s}   (teacher forced, rel-L2 vs fp32 oracle)")
+    for li, (rlayer, hlayer) in enumerate(zip((rv.layer1, rv.layer2, rv.layer3, rv.layer4),
+                                              (hv.layer1, hv.layer2, hv.layer3, hv.layer4))):
+        for bi, (rblk, hblk) in enumerate(zip(rlayer, hlayer)):
+            xin = rb(x.detach()).requires_grad_()
+            out = rblk(xin)
+            dout = rb(torch.randn(out.shape, generator=g))
+            for p in rblk.parameters():
+                p.grad = None
+            out.backward(dout)
+            C = xin.shape[1]
+            thw = tuple(xin.shape[2:])
+            with torch.no_grad():
+                z, thw_o, tape = PV.run_plan(PV.VideoResNet.block_plan(hblk), to_cl(xin.detach(), L.cpad(C)), thw, B, True, True)
+                grads = {}
+                dx = PV.trunk_backward(tape, to_cl(dout, z.shape[1]), grads)
+            torch.cuda.synchronize()
+            ef = rel(from_cl(z, B, thw_o, out.shape[1]), out)
+            eb = rel(from_cl(dx, B, thw, C), xin.grad)
+            ew = max(rel(grads[ph], pr.grad) for pr, ph in zip(rblk.parameters(), hblk.parameters()))
+            print(f"layer{li + 1}.{bi}  {ef:8.4f} {eb:8.4f} {ew:9.4f}", flush=True)
+            x = out.detach()
 
 
 if __name__ == "__main__":
