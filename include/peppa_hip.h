@@ -23,6 +23,11 @@ enum pp_act { PP_ACT_NONE = 0, PP_ACT_GELU = 1, PP_ACT_RELU = 2 };
 enum pp_gather_mode { PP_DENSE = 0, PP_CONV_FWD = 1, PP_CONV_DGRAD = 2 };
 
 int pp_version(void);
+/* The 16-bit operand / activation type of THIS library: libpeppa_hip.so = bf16 (BASELINE configs[1]),
+ * libpeppa_hip_f16.so = the same sources built with -DPP_F16, IEEE half as in the reference's `precision: 16` AMP runs
+ * (hparams_base.yaml:45, BASELINE configs[4]).  Wherever this header says "bf16" for an operand it means that type. */
+enum pp_dtype_t { PP_DTYPE_BF16 = 0, PP_DTYPE_F16 = 1 };
+int pp_dtype(void);
 /* tuning switches (process-wide; also PEPPA_HIP_OPTIONS="name=value,..." through the Python loader):
  *   "xcd_remap_igemm", "xcd_remap_wgrad"  0/1   XCD-contiguous tile order
  *   "persistent_igemm"                    0/1   persistent workgroups with cross-tile prefetch (plain epilogues)
@@ -313,6 +318,17 @@ int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const lo
                      int n_chunks, int chunk, float* norms /* [n_tensors] scratch */, float lr_scheduled,
                      float b1, float b2, float eps, float weight_decay, float max_grad_norm,
                      const float* lr_per_tensor, pp_stream_t s);
+
+/* ---- dynamic loss scaling for the fp16 build (what Lightning's native AMP does around `BertAdam.step` under
+ *      `precision: 16`, /root/reference/hparams_base.yaml:45; torch.cuda.amp.GradScaler semantics) -------------------- */
+/* g *= inv_scale[0] for every tensor of the list, in place; found_inf[0] = 1.0 if any element is inf / nan (else untouched:
+ * zero it first).  = torch._amp_foreach_non_finite_check_and_unscale_.  Only tl->g and tl->numel are read. */
+int pp_grad_unscale_check(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off, int n_chunks,
+                          int chunk, const float* inv_scale, float* found_inf, pp_stream_t s);
+/* scale / growth_tracker update after a step (= torch._amp_update_scale_): found_inf -> scale *= backoff, tracker = 0;
+ * else tracker += 1 and, once it reaches growth_interval, scale *= growth (kept if the product overflows), tracker = 0. */
+int pp_amp_update_scale(float* scale, int* growth_tracker, const float* found_inf, float growth_factor,
+                        float backoff_factor, int growth_interval, pp_stream_t s);
 
 #ifdef __cplusplus
 }

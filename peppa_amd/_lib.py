@@ -8,6 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpeppa_hip.so")
+# one shared object per 16-bit operand type (same sources, include/peppa_hip.h `pp_dtype`)
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libpeppa_hip_f16.so")}
+PRECISION = "bf16"    # which of the two `call` dispatches to (peppa_amd.hip.set_precision)
 
 
 class PeppaHipError(RuntimeError):
@@ -53,6 +56,9 @@ P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 # name -> argtypes (everything returns int status unless listed in _RESTYPE)
 SIGNATURES = {
     "pp_version": [],
+    "pp_dtype": [],
+    "pp_grad_unscale_check": [C.POINTER(TensorList), P, P, I, I, P, P, P],
+    "pp_amp_update_scale": [P, P, P, F, F, I, P],
     "pp_last_error": [],
     "pp_set_option": [C.c_char_p, I],
     "pp_igemm": [C.POINTER(IGemmDesc), P],
@@ -119,31 +125,35 @@ SIGNATURES = {
     "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P, P],
 }
 _RESTYPE = {"pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z}
-_NO_STATUS = set(_RESTYPE) | {"pp_version"}
+_NO_STATUS = set(_RESTYPE) | {"pp_version", "pp_dtype"}
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """Load (once) and return the shared library; fail loudly if it is not built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(precision=None):
+    """Load (once) and return the shared library of `precision` ("bf16" | "fp16", default: the current one); fail
+    loudly if it is not built."""
+    precision = PRECISION if precision is None else precision
+    if precision not in _libs:
+        path = LIB_PATHS[precision]
+        if not os.path.exists(path):
             raise PeppaHipError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). peppa_amd has no CPU/PyTorch fallback.")
-        h = C.CDLL(LIB_PATH)
+        h = C.CDLL(path)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the header and the .so disagree
             fn.argtypes = argtypes
             fn.restype = _RESTYPE.get(name, C.c_int)
-        _lib = h
+        if h.pp_dtype() != {"bf16": 0, "fp16": 1}[precision]:
+            raise PeppaHipError(f"{path} was not built for {precision} operands (pp_dtype = {h.pp_dtype()})")
+        _libs[precision] = h
         # tuning switches for A/B measurements: PEPPA_HIP_OPTIONS="ring_igemm=0,xcd_remap_wgrad=0"
         for item in filter(None, os.environ.get("PEPPA_HIP_OPTIONS", "").split(",")):
             key, _, val = item.partition("=")
             if h.pp_set_option(key.strip().encode(), int(val)) != 0:
                 raise PeppaHipError(f"PEPPA_HIP_OPTIONS: {h.pp_last_error().decode()}")
-    return _lib
+    return _libs[precision]
 
 
 def call(name, *args):

@@ -18,7 +18,7 @@ from torch import nn
 
 from . import hip as H
 from . import layers as L
-from .hip import bf16, f32
+from .hip import act16, f32
 from .dist import grad_dict
 
 CONV_SPEC = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
@@ -184,7 +184,7 @@ class _Drop:
 
 # ---------------------------------------------------------------------------------------------------
 def _fe_forward(fe, wave, save):
-    """wave fp32 [B][L] -> features bf16 [B*T][512]; tape for backward."""
+    """wave fp32 [B][L] -> features 16-bit [B*T][512]; tape for backward."""
     B, Lw = wave.shape
     t = _Rec()
     t.B, t.L = B, Lw
@@ -194,7 +194,7 @@ def _fe_forward(fe, wave, save):
     t.w0 = blk0.conv.weight.reshape(512, 10)
     t.stats = L.zeros((B, 512, 2), f32, wave)
     H.conv0_stats(wave, B, Lw, T0, t.w0, t.stats)
-    cur = L.empty((B * T0, 512), bf16, wave)
+    cur = L.empty((B * T0, 512), act16(), wave)
     H.conv0_apply(wave, B, Lw, T0, t.w0, t.stats, blk0.layer_norm.weight, blk0.layer_norm.bias, blk0.layer_norm.eps, cur)
     t.wave, t.layers = wave, []
     Tcur = T0
@@ -202,7 +202,7 @@ def _fe_forward(fe, wave, save):
         k, s = blk.conv.kernel_size[0], blk.conv.stride[0]
         geom = L.ConvGeom(B, (Tcur, 1, 1), 512, 512, (k, 1, 1), (s, 1, 1), (0, 0, 0))
         wf, wd = L.prep_conv_weights(blk.conv.weight, geom, need_dgrad=save)
-        pre = L.empty((geom.M, 512), bf16, wave) if save else None
+        pre = L.empty((geom.M, 512), act16(), wave) if save else None
         y, _ = L.conv_fwd(cur, geom, wf, act=H.ACT_GELU, pre=pre)
         r = _Rec()
         r.blk, r.geom, r.wd, r.x, r.pre = blk, geom, wd, cur, pre
@@ -215,7 +215,7 @@ def _fe_forward(fe, wave, save):
 def _fe_backward(fe, t, dfeat, grads):
     cur = dfeat
     for r in reversed(t.layers):
-        du = L.empty(cur.shape, bf16, cur)
+        du = L.empty(cur.shape, act16(), cur)
         H.gelu_bwd(cur, r.pre, du)
         if r.blk.conv.weight.requires_grad:
             grads[r.blk.conv.weight] = L.conv_wgrad(r.x, du, r.geom, r.blk.conv.weight.shape)
@@ -235,8 +235,8 @@ def _prep_qkv(att, need_dgrad, batch):
     """q/k/v projections fused into one [2304][768] operand (+ its transpose) and one bias vector (jobs of `batch`)."""
     lins = (att.q_proj, att.k_proj, att.v_proj)
     w0 = lins[0].weight
-    wf = L.empty((2304, 768), bf16, w0)
-    wt = L.empty((768, 2304), bf16, w0) if need_dgrad else None
+    wf = L.empty((2304, 768), act16(), w0)
+    wt = L.empty((768, 2304), act16(), w0) if need_dgrad else None
     bias = L.empty((2304,), f32, w0)
     for i, lin in enumerate(lins):
         batch.cast(lin.weight, wf[i * 768:], 768, 768, 768, 768, 768, 768)
@@ -247,7 +247,7 @@ def _prep_qkv(att, need_dgrad, batch):
 
 
 def _prep_encoder_weights(enc, save):
-    """Every Linear operand of the encoder (bf16 [N][K] and, for the backward pass, its transpose) in ONE launch."""
+    """Every Linear operand of the encoder (16-bit [N][K] and, for the backward pass, its transpose) in ONE launch."""
     fp, tr = enc.feature_projection, enc.transformer
     batch = L.CastBatch()
     w = {"proj": batch.linear(fp.projection.weight, save), "readout": batch.linear(enc.readout.weight, save)}
@@ -263,11 +263,11 @@ FUSED_ATTENTION = True   # one launch per direction (pp_attention_*) when T <= 1
 
 
 def _attention_fwd(qkv, B, T, Tp, scale, save, drop=(0.0, 0)):
-    """qkv bf16 [B*T][2304] -> ctx bf16 [B*T][768]; returns saved P (before attention dropout), or None (fused path:
+    """qkv 16-bit [B*T][2304] -> ctx 16-bit [B*T][768]; returns saved P (before attention dropout), or None (fused path:
     the backward recomputes the probabilities)."""
     Hn, Dh, D3 = NUM_HEADS, 64, 2304
     if FUSED_ATTENTION and T <= 128:
-        ctx = L.empty((B * T, 768), bf16, qkv)
+        ctx = L.empty((B * T, 768), act16(), qkv)
         H.attention_fwd(qkv, B, T, Hn, scale, drop[0], drop[1], ctx)
         return ctx, None
     nb = B * Hn
@@ -275,30 +275,30 @@ def _attention_fwd(qkv, B, T, Tp, scale, save, drop=(0.0, 0)):
     q, k, v = qkv, qkv[:, 768:], qkv[:, 1536:]   # column views (pointer offsets only)
     H.igemm(q, k, S, T, T, Dh, H.gather_dense(D3), D3, Tp, nbatch=nb, inner=Hn, a_s=(T * D3, Dh), b_s=(T * D3, Dh),
             c_s=(Hn * T * Tp, T * Tp))
-    P = L.empty((nb, T, Tp), bf16, qkv)
+    P = L.empty((nb, T, Tp), act16(), qkv)
     H.softmax_fwd(S, Tp, P, Tp, nb, T, scale)
-    Vt = L.empty((nb, Dh, Tp), bf16, qkv)
+    Vt = L.empty((nb, Dh, Tp), act16(), qkv)
     H.transpose_bf16(v, T * D3, D3, Vt, Hn * Dh * Tp, Tp, nb, T, Dh, inner=Hn, in_s1=Dh, out_s1=Dh * Tp)
     Pd = P
     if drop[0] > 0:
-        Pd = L.empty(P.shape, bf16, qkv)
+        Pd = L.empty(P.shape, act16(), qkv)
         H.dropout_bf16(P, Pd, drop[0], drop[1])
-    ctx = L.empty((B * T, 768), bf16, qkv)
+    ctx = L.empty((B * T, 768), act16(), qkv)
     H.igemm(Pd, Vt, ctx, T, Dh, Tp, H.gather_dense(Tp), Tp, 768, nbatch=nb, inner=Hn, a_s=(Hn * T * Tp, T * Tp),
             b_s=(Hn * Dh * Tp, Dh * Tp), c_s=(T * 768, Dh))
     return ctx, (P if save else None)
 
 
 def _attention_bwd(dctx, qkv, P, B, T, Tp, scale, drop=(0.0, 0)):
-    """-> dqkv bf16 [B*T][2304]."""
+    """-> dqkv 16-bit [B*T][2304]."""
     Hn, Dh, D3 = NUM_HEADS, 64, 2304
     if P is None:   # forward ran fused
-        dqkv = L.empty((B * T, D3), bf16, qkv)
+        dqkv = L.empty((B * T, D3), act16(), qkv)
         H.attention_bwd(qkv, dctx, B, T, Hn, scale, drop[0], drop[1], dqkv)
         return dqkv
     nb = B * Hn
     q, k, v = qkv, qkv[:, 768:], qkv[:, 1536:]
-    dqkv = L.empty((B * T, D3), bf16, qkv)
+    dqkv = L.empty((B * T, D3), act16(), qkv)
     dq, dk, dv = dqkv, dqkv[:, 768:], dqkv[:, 1536:]
     # dP = dctx V^T
     dP = L.empty((nb, T, Tp), f32, qkv)
@@ -307,27 +307,27 @@ def _attention_bwd(dctx, qkv, P, B, T, Tp, scale, drop=(0.0, 0)):
     Pd = P
     if drop[0] > 0:   # same mask as the forward pass: dP through the dropout, dV from the dropped probabilities
         H.dropout_f32(dP, dP, drop[0], drop[1])
-        Pd = L.empty(P.shape, bf16, qkv)
+        Pd = L.empty(P.shape, act16(), qkv)
         H.dropout_bf16(P, Pd, drop[0], drop[1])
     # dV = Pd^T dctx
-    Pt = L.empty((nb, T, Tp), bf16, qkv)
+    Pt = L.empty((nb, T, Tp), act16(), qkv)
     H.transpose_bf16(Pd, T * Tp, Tp, Pt, T * Tp, Tp, nb, T, T)
-    dOt = L.empty((nb, Dh, Tp), bf16, qkv)
+    dOt = L.empty((nb, Dh, Tp), act16(), qkv)
     H.transpose_bf16(dctx, T * 768, 768, dOt, Hn * Dh * Tp, Tp, nb, T, Dh, inner=Hn, in_s1=Dh, out_s1=Dh * Tp)
     H.igemm(Pt, dOt, dv, T, Dh, Tp, H.gather_dense(Tp), Tp, D3, nbatch=nb, inner=Hn, a_s=(Hn * T * Tp, T * Tp),
             b_s=(Hn * Dh * Tp, Dh * Tp), c_s=(T * D3, Dh))
     # dS = softmax'(P, dP)
-    dS = L.empty((nb, T, Tp), bf16, qkv)
+    dS = L.empty((nb, T, Tp), act16(), qkv)
     H.softmax_bwd(dP, Tp, P, Tp, dS, nb, T, scale)
     # dQ = dS K
-    Kt = L.empty((nb, Dh, Tp), bf16, qkv)
+    Kt = L.empty((nb, Dh, Tp), act16(), qkv)
     H.transpose_bf16(k, T * D3, D3, Kt, Hn * Dh * Tp, Tp, nb, T, Dh, inner=Hn, in_s1=Dh, out_s1=Dh * Tp)
     H.igemm(dS, Kt, dq, T, Dh, Tp, H.gather_dense(Tp), Tp, D3, nbatch=nb, inner=Hn, a_s=(Hn * T * Tp, T * Tp),
             b_s=(Hn * Dh * Tp, Dh * Tp), c_s=(T * D3, Dh))
     # dK = dS^T Q
-    dSt = L.empty((nb, T, Tp), bf16, qkv)
+    dSt = L.empty((nb, T, Tp), act16(), qkv)
     H.transpose_bf16(dS, T * Tp, Tp, dSt, T * Tp, Tp, nb, T, T)
-    Qt = L.empty((nb, Dh, Tp), bf16, qkv)
+    Qt = L.empty((nb, Dh, Tp), act16(), qkv)
     H.transpose_bf16(q, T * D3, D3, Qt, Hn * Dh * Tp, Tp, nb, T, Dh, inner=Hn, in_s1=Dh, out_s1=Dh * Tp)
     H.igemm(dSt, Qt, dk, T, Dh, Tp, H.gather_dense(Tp), Tp, D3, nbatch=nb, inner=Hn, a_s=(Hn * T * Tp, T * Tp),
             b_s=(Hn * Dh * Tp, Dh * Tp), c_s=(T * D3, Dh))
@@ -335,7 +335,7 @@ def _attention_bwd(dctx, qkv, P, B, T, Tp, scale, drop=(0.0, 0)):
 
 
 def _enc_forward(enc, feat, B, T, save, training=False):
-    """feat bf16 [B*T][512] -> out fp32 [B*T][num_out]; tape."""
+    """feat 16-bit [B*T][512] -> out fp32 [B*T][num_out]; tape."""
     M = B * T
     Tp = L.cpad(T)
     t = _Rec()
@@ -357,11 +357,11 @@ def _enc_forward(enc, feat, B, T, save, training=False):
     geom = L.ConvGeom(B, (T, 1, 1), 768, 768, (pc.kernel, 1, 1), (1, 1, 1), (pc.kernel // 2, 0, 0), groups=pc.groups, To=T)
     Cig = 768 // pc.groups
     t.wn_norm = L.empty((pc.kernel,), f32, feat)
-    wfp = L.empty((768, pc.kernel, Cig), bf16, feat)
+    wfp = L.empty((768, pc.kernel, Cig), act16(), feat)
     H.weightnorm_fwd(conv.weight_v, conv.weight_g.reshape(-1), 768, Cig, pc.kernel, t.wn_norm, wfp)
     t.pc_geom = geom
-    t.pc_pre = L.empty((M, 768), bf16, feat) if save else None
-    x1 = L.empty((M, 768), bf16, feat)
+    t.pc_pre = L.empty((M, 768), act16(), feat) if save else None
+    x1 = L.empty((M, 768), act16(), feat)
     H.igemm(x0, wfp, x1, M, geom.Cog, geom.Kf, geom.g_fwd(), geom.Kf, 768, b_rows=geom.Cog, bias=conv.bias,
             act=H.ACT_GELU, Cpre=t.pc_pre, residual=x0, ldr=768, nbatch=pc.groups, inner=1, a_s=(Cig, 0),
             b_s=(geom.Cog * geom.Kf, 0), c_s=(geom.Cog, 0), bias_s=(geom.Cog, 0))
@@ -389,7 +389,7 @@ def _enc_forward(enc, feat, B, T, save, training=False):
         xa, r.lnA = L.layernorm_fwd(s1, layer.layer_norm, layer.layer_norm.eps)
         r.s1, r.xa = s1, xa
         wf, r.ff1_wt = w_ff1
-        r.u = L.empty((M, 3072), bf16, feat) if save else None
+        r.u = L.empty((M, 3072), act16(), feat) if save else None
         h = L.linear_fwd(xa, M, wf, 3072, bias=ff.intermediate_dense.bias, act=H.ACT_GELU, pre=r.u, dropout=r.d_int)
         r.h = h
         wf, r.ff2_wt = w_ff2
@@ -423,12 +423,12 @@ def _ln_bwd(grads, ln, dy, x, saved):
 
 
 def _enc_backward(enc, t, dout, grads):
-    """dout fp32 [M][num_out] -> dfeat bf16 [M][512]."""
+    """dout fp32 [M][num_out] -> dfeat 16-bit [M][512]."""
     M, B, T, Tp = t.M, t.B, t.T, t.Tp
     fp, tr = enc.feature_projection, enc.transformer
     n_out = enc.readout.out_features
     Np = L.cpad(n_out)
-    dy = L.empty((M, Np), bf16, dout)
+    dy = L.empty((M, Np), act16(), dout)
     H.cast_pad_2d(dout, dy, M, n_out, n_out, M, Np)
     _lin_grads(grads, enc.readout, t.x_final, dy, M, n_out, 768)
     dx = L.linear_dgrad(dy, M, t.ro_wt, 768)
@@ -438,11 +438,11 @@ def _enc_backward(enc, t, dout, grads):
         ds2 = _ln_bwd(grads, layer.final_layer_norm, dx, r.s2, r.lnB)
         dt2 = ds2
         if r.d_ffo[0] > 0:
-            dt2 = L.empty(ds2.shape, bf16, ds2)
+            dt2 = L.empty(ds2.shape, act16(), ds2)
             H.dropout_bf16(ds2, dt2, *r.d_ffo)
         _lin_grads(grads, ff.output_dense, r.h, dt2, M, 768, 3072)
         dh = L.linear_dgrad(dt2, M, r.ff2_wt, 3072)
-        du = L.empty(dh.shape, bf16, dh)
+        du = L.empty(dh.shape, act16(), dh)
         if r.d_int[0] > 0:
             H.gelu_bwd_dropout(dh, r.u, du, *r.d_int)      # dropout mask and GELU derivative in one pass
         else:
@@ -452,7 +452,7 @@ def _enc_backward(enc, t, dout, grads):
         ds1 = _ln_bwd(grads, layer.layer_norm, dxa, r.s1, r.lnA)
         dt1 = ds1
         if r.d_out[0] > 0:
-            dt1 = L.empty(ds1.shape, bf16, ds1)
+            dt1 = L.empty(ds1.shape, act16(), ds1)
             H.dropout_bf16(ds1, dt1, *r.d_out)
         _lin_grads(grads, att.out_proj, r.ctx, dt1, M, 768, 768)
         dctx = L.linear_dgrad(dt1, M, r.out_wt, 768)
@@ -474,7 +474,7 @@ def _enc_backward(enc, t, dout, grads):
     conv = pc.conv
     geom = t.pc_geom
     Cig = 768 // pc.groups
-    du = L.empty((M, 768), bf16, dx1)
+    du = L.empty((M, 768), act16(), dx1)
     H.gelu_bwd(dx1, t.pc_pre, du)
     if conv.weight_v.requires_grad:
         gw = L.conv_wgrad_raw(t.x0, du, geom)                      # [768][K][Cig]
@@ -485,13 +485,13 @@ def _enc_backward(enc, t, dout, grads):
         H.colsum_bf16(du, M, 768, 768, db)
         grads[conv.bias] = db
     # dgrad of the grouped conv, + dx1 (residual path)
-    wd = L.empty((pc.groups, Cig, pc.kernel, geom.Cog), bf16, du)
+    wd = L.empty((pc.groups, Cig, pc.kernel, geom.Cog), act16(), du)
     wfp4 = t.wfp.view(pc.groups, geom.Cog, pc.kernel, Cig)
     for gi in range(pc.groups):
         # [Cog][K][Cig] -> [Cig][K][Cog]: transpose of a [Cog] x [K*Cig] matrix regrouped per tap
         H.transpose_bf16(wfp4[gi], Cig, pc.kernel * Cig, wd[gi], geom.Cog, pc.kernel * geom.Cog, pc.kernel, geom.Cog, Cig,
                          r_pad=geom.Cog)
-    dx0 = L.empty((M, 768), bf16, du)
+    dx0 = L.empty((M, 768), act16(), du)
     H.igemm(du, wd, dx0, M, Cig, geom.Kd, geom.g_dgrad(), geom.Kd, 768, b_rows=Cig, residual=dx1, ldr=768,
             nbatch=pc.groups, inner=1, a_s=(geom.Cog, 0), b_s=(Cig * geom.Kd, 0), c_s=(Cig, 0))
     if t.d_fp[0] > 0:
@@ -535,7 +535,7 @@ class Wav2Vec2Fn(torch.autograd.Function):
                 t = ctx.enc_tape
                 dfeat = _enc_backward(model.encoder, t, dout.view(t.M, -1), grads)
             else:
-                dfeat = L.empty((dout.numel() // 512, 512), bf16, dout)
+                dfeat = L.empty((dout.numel() // 512, 512), act16(), dout)
                 H.cast_f32_to_bf16(dout.view(-1, 512), dfeat)
             if any(p.requires_grad for p in fe.parameters()):
                 _fe_backward(fe, ctx.fe_tape, dfeat, grads)

@@ -25,7 +25,6 @@ constexpr int PS = 288;                 // row stride of the [128][128] tiles: 3
 constexpr int QK_BYTES = TT * QS;
 constexpr int P_BYTES = TT * PS;
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
@@ -39,17 +38,17 @@ __device__ __forceinline__ bool keep_elem(uint32_t seed, long long e, uint32_t t
 }
 
 // fragment of an operand stored [row][k] (k contiguous): lane l -> row (l & 15), k = k0 + 8 (l >> 4) .. + 7
-__device__ __forceinline__ bf16x8 frag_rowmajor(const unsigned char* tile, int stride, int row0, int k0, int lane) {
-  return *(const bf16x8*)(tile + (row0 + (lane & 15)) * stride + (k0 + 8 * (lane >> 4)) * 2);
+__device__ __forceinline__ h16x8 frag_rowmajor(const unsigned char* tile, int stride, int row0, int k0, int lane) {
+  return *(const h16x8*)(tile + (row0 + (lane & 15)) * stride + (k0 + 8 * (lane >> 4)) * 2);
 }
 // fragment of an operand stored [k][col] (k is the slow axis): same register layout as above -- lane l receives column
 // (l & 15) for k = k0 + 8 (l >> 4) .. + 7 -- through two transposing reads (lane 4q+p of a 16-lane group supplies the
 // address of k-row q, columns 4p .. 4p+3)
-__device__ __forceinline__ bf16x8 frag_kmajor(const unsigned char* tile, int stride, int col0, int k0, int lane) {
+__device__ __forceinline__ h16x8 frag_kmajor(const unsigned char* tile, int stride, int col0, int k0, int lane) {
   const int g = lane >> 4, li = lane & 15;
   const unsigned char* a0 = tile + (k0 + 8 * g + (li >> 2)) * stride + (col0 + 4 * (li & 3)) * 2;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * stride));
+  const h16x4 lo = ds_read_tr16(a0);
+  const h16x4 hi = ds_read_tr16(a0 + 4 * stride);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -65,10 +64,10 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 struct AttnArgs {
-  const bfraw* qkv;     // [B*T][3*Hn*64]: q | k | v
-  const bfraw* dctx;    // backward: [B*T][Hn*64]
-  bfraw* ctx;           // forward out [B*T][Hn*64]
-  bfraw* dqkv;          // backward out [B*T][3*Hn*64]
+  const h16raw* qkv;     // [B*T][3*Hn*64]: q | k | v
+  const h16raw* dctx;    // backward: [B*T][Hn*64]
+  h16raw* ctx;           // forward out [B*T][Hn*64]
+  h16raw* dqkv;          // backward out [B*T][3*Hn*64]
   int T, Tp, Hn;
   float scale;          // applied to the scores
   uint32_t drop_thr;    // p * 65536 (0 = no dropout)
@@ -78,7 +77,7 @@ struct AttnArgs {
 
 // load one [T][64] head slice (row stride ld elements) into a zero-padded [128][64] LDS tile
 template <int NTH>
-__device__ __forceinline__ void load_tile(unsigned char* tile, const bfraw* src, int ld, int T, int tid) {
+__device__ __forceinline__ void load_tile(unsigned char* tile, const h16raw* src, int ld, int T, int tid) {
 #pragma unroll
   for (int i = 0; i < TT / (NTH / 8); ++i) {
     const int row = (tid >> 3) + (NTH / 8) * i, ch = tid & 7;
@@ -99,14 +98,14 @@ __device__ __forceinline__ void scores_softmax(const AttnArgs& p, const unsigned
     for (int nt = 0; nt < 8; ++nt) P[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 aq[MT];
+    h16x8 aq[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) aq[mt] = frag_rowmajor(Qs, QS, wave * (16 * MT) + mt * 16, ks * 32, lane);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      const bf16x8 bk = frag_rowmajor(Ks, QS, nt * 16, ks * 32, lane);
+      const h16x8 bk = frag_rowmajor(Ks, QS, nt * 16, ks * 32, lane);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) P[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[mt], bk, P[mt][nt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) P[mt][nt] = PP_MFMA16(aq[mt], bk, P[mt][nt], 0, 0, 0);
     }
   }
   // accumulator layout: column j = fr + 16 nt, rows t = 16 MT wave + 16 mt + 4 fq + r
@@ -137,19 +136,19 @@ __device__ __forceinline__ void scores_softmax(const AttnArgs& p, const unsigned
         const int j = fr + 16 * nt;
         const float pr = P[mt][nt][r] * inv;
         P[mt][nt][r] = pr;
-        float pd = bf2f(f2bf(pr));       // the unfused path rounds P to bf16 before the dropout
+        float pd = h2f(f2h(pr));       // the unfused path rounds P to bf16 before the dropout
         if (p.drop_thr) pd = keep_elem(p.seed, ((long long)bh * p.T + t) * p.Tp + j, p.drop_thr) ? pd * p.drop_scale : 0.f;
-        *(bfraw*)(Ps + t * PS + j * 2) = (t < p.T) ? f2bf(pd) : (bfraw)0;
+        *(h16raw*)(Ps + t * PS + j * 2) = (t < p.T) ? f2h(pd) : (h16raw)0;
       }
     }
 }
 
 // out[(row)][c0 + 4 fq .. + 3] (bf16, row stride ld) from a transposed accumulator tile: lane column = row (fr), rows = channels
-__device__ __forceinline__ void store_t(bfraw* out, long long ld, int row, int T, int ch, const f32x4& a) {
+__device__ __forceinline__ void store_t(h16raw* out, long long ld, int row, int T, int ch, const f32x4& a) {
   if (row < T) {
     uint2 v;
-    v.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
-    v.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
+    v.x = (uint32_t)f2h(a[0]) | ((uint32_t)f2h(a[1]) << 16);
+    v.y = (uint32_t)f2h(a[2]) | ((uint32_t)f2h(a[3]) << 16);
     *(uint2*)(out + (long long)row * ld + ch) = v;
   }
 }
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd_kernel(const AttnArgs p)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / p.Hn, h = bh % p.Hn;
   const int D = p.Hn * DH, D3 = 3 * D;
-  const bfraw* base = p.qkv + (long long)b * p.T * D3 + h * DH;
+  const h16raw* base = p.qkv + (long long)b * p.T * D3 + h * DH;
   load_tile<256>(Qs, base, D3, p.T, tid);
   load_tile<256>(Ks, base + D, D3, p.T, tid);
   load_tile<256>(Vs, base + 2 * D, D3, p.T, tid);
@@ -177,18 +176,18 @@ __global__ __launch_bounds__(256, 1) void attention_fwd_kernel(const AttnArgs p)
   for (int nd = 0; nd < 4; ++nd) O[nd][0] = O[nd][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kj = 0; kj < 4; ++kj) {
-    bf16x8 ap[2];
+    h16x8 ap[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) ap[mt] = frag_rowmajor(Ps, PS, wave * 32 + mt * 16, kj * 32, lane);
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) {
-      const bf16x8 bv = frag_kmajor(Vs, QS, nd * 16, kj * 32, lane);
-      O[nd][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, ap[0], O[nd][0], 0, 0, 0);
-      O[nd][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, ap[1], O[nd][1], 0, 0, 0);
+      const h16x8 bv = frag_kmajor(Vs, QS, nd * 16, kj * 32, lane);
+      O[nd][0] = PP_MFMA16(bv, ap[0], O[nd][0], 0, 0, 0);
+      O[nd][1] = PP_MFMA16(bv, ap[1], O[nd][1], 0, 0, 0);
     }
   }
   const int fr = lane & 15, fq = lane >> 4;
-  bfraw* out = p.ctx + (long long)b * p.T * D + h * DH;
+  h16raw* out = p.ctx + (long long)b * p.T * D + h * DH;
 #pragma unroll
   for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(BNT, 1) void attention_bwd_kernel(const AttnArgs p)
   const int fr = lane & 15, fq = lane >> 4;
   const int bh = blockIdx.x, b = bh / p.Hn, h = bh % p.Hn;
   const int D = p.Hn * DH, D3 = 3 * D;
-  const bfraw* base = p.qkv + (long long)b * p.T * D3 + h * DH;
+  const h16raw* base = p.qkv + (long long)b * p.T * D3 + h * DH;
   load_tile<BNT>(Qs, base, D3, p.T, tid);
   load_tile<BNT>(Ks, base + D, D3, p.T, tid);
   load_tile<BNT>(Vs, base + 2 * D, D3, p.T, tid);
@@ -227,14 +226,14 @@ __global__ __launch_bounds__(BNT, 1) void attention_bwd_kernel(const AttnArgs p)
     for (int nt = 0; nt < 8; ++nt) dP[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 ao[BMT];
+    h16x8 ao[BMT];
 #pragma unroll
     for (int mt = 0; mt < BMT; ++mt) ao[mt] = frag_rowmajor(Os, QS, wave * (16 * BMT) + mt * 16, ks * 32, lane);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      const bf16x8 bv = frag_rowmajor(Vs, QS, nt * 16, ks * 32, lane);
+      const h16x8 bv = frag_rowmajor(Vs, QS, nt * 16, ks * 32, lane);
 #pragma unroll
-      for (int mt = 0; mt < BMT; ++mt) dP[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[mt], bv, dP[mt][nt], 0, 0, 0);
+      for (int mt = 0; mt < BMT; ++mt) dP[mt][nt] = PP_MFMA16(ao[mt], bv, dP[mt][nt], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -249,21 +248,21 @@ __global__ __launch_bounds__(BNT, 1) void attention_bwd_kernel(const AttnArgs p)
         float d = dP[mt][nt][r];
         if (p.drop_thr) d = keep_elem(p.seed, ((long long)bh * p.T + t) * p.Tp + j, p.drop_thr) ? d * p.drop_scale : 0.f;
         dP[mt][nt][r] = d;
-        dot += d * bf2f(f2bf(P[mt][nt][r]));   // (the unfused path keeps P in bf16)
+        dot += d * h2f(f2h(P[mt][nt][r]));   // (the unfused path keeps P in bf16)
       }
       dot = group16_sum(dot);
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
         const int j = fr + 16 * nt;
-        const float ds = p.scale * bf2f(f2bf(P[mt][nt][r])) * (dP[mt][nt][r] - dot);
-        *(bfraw*)(Ss + t * PS + j * 2) = (t < p.T && j < p.T) ? f2bf(ds) : (bfraw)0;
+        const float ds = p.scale * h2f(f2h(P[mt][nt][r])) * (dP[mt][nt][r] - dot);
+        *(h16raw*)(Ss + t * PS + j * 2) = (t < p.T && j < p.T) ? f2h(ds) : (h16raw)0;
       }
     }
   __syncthreads();   // Pd and dS of every row are in LDS
 
-  bfraw* dq = p.dqkv + (long long)b * p.T * D3 + h * DH;
-  bfraw* dk = dq + D;
-  bfraw* dv = dq + 2 * D;
+  h16raw* dq = p.dqkv + (long long)b * p.T * D3 + h * DH;
+  h16raw* dk = dq + D;
+  h16raw* dv = dq + 2 * D;
   f32x4 acc[4][BMT];
   auto zero = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -275,14 +274,14 @@ __global__ __launch_bounds__(BNT, 1) void attention_bwd_kernel(const AttnArgs p)
   zero();
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
-    bf16x8 bp[BMT];
+    h16x8 bp[BMT];
 #pragma unroll
     for (int mt = 0; mt < BMT; ++mt) bp[mt] = frag_kmajor(Ps, PS, wave * (16 * BMT) + mt * 16, kt * 32, lane);
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) {
-      const bf16x8 ao = frag_kmajor(Os, QS, nd * 16, kt * 32, lane);
+      const h16x8 ao = frag_kmajor(Os, QS, nd * 16, kt * 32, lane);
 #pragma unroll
-      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, bp[mt], acc[nd][mt], 0, 0, 0);
+      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = PP_MFMA16(ao, bp[mt], acc[nd][mt], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -293,14 +292,14 @@ __global__ __launch_bounds__(BNT, 1) void attention_bwd_kernel(const AttnArgs p)
   zero();
 #pragma unroll
   for (int kj = 0; kj < 4; ++kj) {
-    bf16x8 bs[BMT];
+    h16x8 bs[BMT];
 #pragma unroll
     for (int mt = 0; mt < BMT; ++mt) bs[mt] = frag_rowmajor(Ss, PS, wave * (16 * BMT) + mt * 16, kj * 32, lane);
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) {
-      const bf16x8 ak = frag_kmajor(Ks, QS, nd * 16, kj * 32, lane);
+      const h16x8 ak = frag_kmajor(Ks, QS, nd * 16, kj * 32, lane);
 #pragma unroll
-      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bs[mt], acc[nd][mt], 0, 0, 0);
+      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = PP_MFMA16(ak, bs[mt], acc[nd][mt], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -311,14 +310,14 @@ __global__ __launch_bounds__(BNT, 1) void attention_bwd_kernel(const AttnArgs p)
   zero();
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
-    bf16x8 bs[BMT];
+    h16x8 bs[BMT];
 #pragma unroll
     for (int mt = 0; mt < BMT; ++mt) bs[mt] = frag_kmajor(Ss, PS, wave * (16 * BMT) + mt * 16, kt * 32, lane);
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) {
-      const bf16x8 aq = frag_kmajor(Qs, QS, nd * 16, kt * 32, lane);
+      const h16x8 aq = frag_kmajor(Qs, QS, nd * 16, kt * 32, lane);
 #pragma unroll
-      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bs[mt], acc[nd][mt], 0, 0, 0);
+      for (int mt = 0; mt < BMT; ++mt) acc[nd][mt] = PP_MFMA16(aq, bs[mt], acc[nd][mt], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -335,7 +334,7 @@ int check(const char* who, const void* qkv, int B, int T, int Hn, float p) {
 
 AttnArgs make_args(const void* qkv, int T, int Hn, float scale, float p, unsigned seed) {
   AttnArgs a;
-  a.qkv = (const bfraw*)qkv; a.dctx = nullptr; a.ctx = nullptr; a.dqkv = nullptr;
+  a.qkv = (const h16raw*)qkv; a.dctx = nullptr; a.ctx = nullptr; a.dqkv = nullptr;
   a.T = T; a.Tp = (T + 15) & ~15; a.Hn = Hn; a.scale = scale;
   a.drop_thr = (uint32_t)(p * 65536.f + 0.5f);
   a.drop_scale = 1.f / (1.f - p);
@@ -350,7 +349,7 @@ extern "C" int pp_attention_fwd(const void* qkv, int B, int T, int heads, float 
   if (int rc = check("pp_attention_fwd", qkv, B, T, heads, drop_p)) return rc;
   PP_CHECK_ARG(ctx != nullptr, "pp_attention_fwd: null output");
   AttnArgs a = make_args(qkv, T, heads, scale, drop_p, seed);
-  a.ctx = (bfraw*)ctx;
+  a.ctx = (h16raw*)ctx;
   hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)s, a);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -361,8 +360,8 @@ extern "C" int pp_attention_bwd(const void* qkv, const void* dctx, int B, int T,
   if (int rc = check("pp_attention_bwd", qkv, B, T, heads, drop_p)) return rc;
   PP_CHECK_ARG(dctx && dqkv, "pp_attention_bwd: null operand");
   AttnArgs a = make_args(qkv, T, heads, scale, drop_p, seed);
-  a.dctx = (const bfraw*)dctx;
-  a.dqkv = (bfraw*)dqkv;
+  a.dctx = (const h16raw*)dctx;
+  a.dqkv = (h16raw*)dqkv;
   hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * heads), dim3(BNT), 0, (hipStream_t)s, a);
   PP_LAUNCH_CHECK();
   return PP_OK;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void col_reduce(long long M, int Cp, int rows_per_blk
   }
 }
 
-__global__ __launch_bounds__(256) void colstats_kernel(const bfraw* __restrict__ y, long long M, int Cp,
+__global__ __launch_bounds__(256) void colstats_kernel(const h16raw* __restrict__ y, long long M, int Cp,
                                                        int rows_per_blk, float* partials) {
   col_reduce<2>(M, Cp, rows_per_blk, partials, [&](long long r, int ch, float (*acc)[8]) {
     const uint4 v = *(const uint4*)(y + r * Cp + ch * 8);
@@ -122,9 +122,9 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, float (&f)[8]
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(const bfraw* __restrict__ y, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, const bfraw* __restrict__ res,
-                                                       int relu, bfraw* __restrict__ z, long long M, int cpr) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const h16raw* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const h16raw* __restrict__ res,
+                                                       int relu, h16raw* __restrict__ z, long long M, int cpr) {
   const int rpb = 256 / cpr;
   const int tid = threadIdx.x;
   if (tid >= rpb * cpr) return;
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bfraw* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bfraw* __restrict__ dz, const bfraw* __restrict__ y,
-                                                            const bfraw* __restrict__ z, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const h16raw* __restrict__ dz, const h16raw* __restrict__ y,
+                                                            const h16raw* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu, long long M, int Cp,
                                                             int rows_per_blk, float* partials) {
@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bfraw* __restrict__ dz, const bfraw* __restrict__ y,
-                                                           const bfraw* __restrict__ z, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const h16raw* __restrict__ dz, const h16raw* __restrict__ y,
+                                                           const h16raw* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ coef,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           int relu, bfraw* __restrict__ dy, bfraw* __restrict__ dres,
+                                                           int relu, h16raw* __restrict__ dy, h16raw* __restrict__ dres,
                                                            long long M, int cpr, int Cp) {
   const int rpb = 256 / cpr;
   const int tid = threadIdx.x;
@@ -317,7 +317,7 @@ extern "C" int pp_colstats_bf16(const void* y, long long M, int Cp, float* parti
   PP_CHECK_ARG(M > 0 && nblk > 0, "pp_colstats_bf16: bad sizes");
   const int rows_per_blk = (int)((M + nblk - 1) / nblk);
   const int rpb = 256 / (Cp / 8);
-  hipLaunchKernelGGL(colstats_kernel, dim3(nblk), dim3(256), (size_t)rpb * 2 * Cp * 4, (hipStream_t)s, (const bfraw*)y, M,
+  hipLaunchKernelGGL(colstats_kernel, dim3(nblk), dim3(256), (size_t)rpb * 2 * Cp * 4, (hipStream_t)s, (const h16raw*)y, M,
                      Cp, rows_per_blk, partials);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -359,8 +359,8 @@ extern "C" int pp_bn_apply(const void* y, const float* scale, const float* shift
                            long long M, int Cp, pp_stream_t s) {
   CHECK_CP(Cp, "pp_bn_apply");
   const long long nchunks = M * (Cp / 8);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const bfraw*)y, scale,
-                     shift, (const bfraw*)res, relu, (bfraw*)z, M, Cp / 8);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const h16raw*)y, scale,
+                     shift, (const h16raw*)res, relu, (h16raw*)z, M, Cp / 8);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -373,7 +373,7 @@ extern "C" int pp_bn_bwd_reduce(const void* dz, const void* y, const void* z, co
   const int rows_per_blk = (int)((M + nblk - 1) / nblk);
   const int rpb = 256 / (Cp / 8);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), (size_t)rpb * 2 * Cp * 4, (hipStream_t)s,
-                     (const bfraw*)dz, (const bfraw*)y, (const bfraw*)z, mean, rstd, scale, shift, relu, M, Cp, rows_per_blk, partials);
+                     (const h16raw*)dz, (const h16raw*)y, (const h16raw*)z, mean, rstd, scale, shift, relu, M, Cp, rows_per_blk, partials);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -392,8 +392,8 @@ extern "C" int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, con
   PP_CHECK_ARG(!relu || z || (scale && shift), "pp_bn_bwd_apply: relu needs z or scale/shift");
   CHECK_CP(Cp, "pp_bn_bwd_apply");
   const long long nchunks = M * (Cp / 8);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const bfraw*)dz,
-                     (const bfraw*)y, (const bfraw*)z, mean, rstd, coef, scale, shift, relu, (bfraw*)dy, (bfraw*)dres, M, Cp / 8, Cp);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const h16raw*)dz,
+                     (const h16raw*)y, (const h16raw*)z, mean, rstd, coef, scale, shift, relu, (h16raw*)dy, (h16raw*)dres, M, Cp / 8, Cp);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

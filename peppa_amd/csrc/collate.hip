@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void collate_rows_kernel(const long long* __re
 
 // uint8 [B][T][H][W][3] -> normalised bf16 [B*T*H*W][8] (channels 3..7 zero): the stem's input, same arithmetic as
 // video_norm_kernel on the fp32 batch ((x/255 - mean) * (1/std), RNE to bf16), so both routes give identical bits.
-__global__ __launch_bounds__(256) void video_norm_u8_kernel(const uint8_t* __restrict__ x, bfraw* __restrict__ out,
+__global__ __launch_bounds__(256) void video_norm_u8_kernel(const uint8_t* __restrict__ x, h16raw* __restrict__ out,
                                                             long long npos, float m0, float m1, float m2, float i0,
                                                             float i1, float i2) {
   __shared__ float lut[256];
@@ -140,7 +140,7 @@ extern "C" int pp_video_normalize_u8_ndhwc(const void* x, void* out, int B, int 
   PP_CHECK_ARG((((uintptr_t)x) & 3) == 0, "pp_video_normalize_u8_ndhwc: x must be 4-byte aligned");
   const long long npos = (long long)B * T * H * W;
   hipLaunchKernelGGL(video_norm_u8_kernel, dim3(grid_x(npos / 4 + 1, 1)), dim3(256), 0, S_, (const uint8_t*)x,
-                     (bfraw*)out, npos, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+                     (h16raw*)out, npos, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -5,10 +5,22 @@
 #include <stdio.h>
 #include "../../include/peppa_hip.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// The 16-bit operand / activation type of this build.  libpeppa_hip.so is built with bf16 (BASELINE configs[1]);
+// the same sources built with -DPP_F16 give libpeppa_hip_f16.so, IEEE half as in the reference's `precision: 16` AMP runs
+// (hparams_base.yaml:45; BASELINE configs[4]).  Both accumulate in fp32 on the matrix cores; statistics, norms, softmax,
+// the heads, the loss and the optimizer are fp32 in either.  (Entry points keep "bf16" in their names in both builds:
+// there it means "the library's 16-bit type"; pp_dtype() tells which.)
+#ifdef PP_F16
+typedef _Float16 h16;
+#define PP_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+typedef __bf16 h16;
+#define PP_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+typedef __attribute__((ext_vector_type(8))) h16 h16x8;
+typedef __attribute__((ext_vector_type(4))) h16 h16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef unsigned short bfraw;  // raw bf16 bits in HBM
+typedef unsigned short h16raw;  // raw bits of the 16-bit type in HBM / LDS
 
 #define PP_WAVE 64
 
@@ -31,15 +43,29 @@ void pp_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
-// ---- bf16 <-> f32 ---------------------------------------------------------------------
-__device__ __forceinline__ float bf2f(bfraw v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bfraw f2bf(float f) {
+// ---- 16-bit <-> f32 ---------------------------------------------------------------------
+#ifdef PP_F16
+__device__ __forceinline__ float h2f(h16raw v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ h16raw f2h(float f) {
+  _Float16 b = (_Float16)f;            // v_cvt_f16_f32: RNE, overflow -> inf (the loss scaler's job to avoid)
+  return __builtin_bit_cast(h16raw, b);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const half2_t h = __builtin_bit_cast(half2_t, w[q]);
+    f[2 * q] = (float)h[0];
+    f[2 * q + 1] = (float)h[1];
+  }
+}
+#else
+__device__ __forceinline__ float h2f(h16raw v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ h16raw f2h(float f) {
   // plain cast lowers to v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
   __bf16 b = (__bf16)f;
-  return __builtin_bit_cast(bfraw, b);
-}
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  return __builtin_bit_cast(h16raw, b);
 }
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
@@ -47,11 +73,21 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
   f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
+#endif
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16);
+}
 __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 v;
   v.x = pack2(f[0], f[1]); v.y = pack2(f[2], f[3]);
   v.z = pack2(f[4], f[5]); v.w = pack2(f[6], f[7]);
   return v;
+}
+// gfx950 transposing LDS read (ds_read_b64_tr_b16) through the type-agnostic i16 builtin
+__device__ __forceinline__ h16x4 ds_read_tr16(const unsigned char* lds_addr) {
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+  return __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)lds_addr));
 }
 
 // Phi(x) = 0.5 (1 + erf(x / sqrt 2)) through Abramowitz & Stegun 7.1.26 (erfc(|u|) = poly(t) e^{-u^2}, absolute error

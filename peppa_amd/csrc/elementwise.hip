@@ -10,7 +10,12 @@ void pp_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* pp_last_error(void) { return g_err; }
-extern "C" int pp_version(void) { return 100; }
+extern "C" int pp_version(void) { return 200; }
+#ifdef PP_F16
+extern "C" int pp_dtype(void) { return PP_DTYPE_F16; }
+#else
+extern "C" int pp_dtype(void) { return PP_DTYPE_BF16; }
+#endif
 
 namespace {
 
@@ -22,7 +27,7 @@ inline int sgrid(long long n, int per = 256) {
 }
 #define GSTRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 
-__global__ void gelu_fwd_kernel(const bfraw* __restrict__ x, bfraw* __restrict__ y, long long nch) {
+__global__ void gelu_fwd_kernel(const h16raw* __restrict__ x, h16raw* __restrict__ y, long long nch) {
   GSTRIDE(i, nch) {
     float f[8];
     unpack8(*(const uint4*)(x + i * 8), f);
@@ -31,7 +36,7 @@ __global__ void gelu_fwd_kernel(const bfraw* __restrict__ x, bfraw* __restrict__
     *(uint4*)(y + i * 8) = pack8(f);
   }
 }
-__global__ void gelu_bwd_kernel(const bfraw* __restrict__ dy, const bfraw* __restrict__ x, bfraw* __restrict__ dx,
+__global__ void gelu_bwd_kernel(const h16raw* __restrict__ dy, const h16raw* __restrict__ x, h16raw* __restrict__ dx,
                                 long long nch) {
   GSTRIDE(i, nch) {
     float f[8], d[8];
@@ -42,7 +47,7 @@ __global__ void gelu_bwd_kernel(const bfraw* __restrict__ dy, const bfraw* __res
     *(uint4*)(dx + i * 8) = pack8(d);
   }
 }
-__global__ void add_kernel(const bfraw* __restrict__ a, const bfraw* __restrict__ b, bfraw* __restrict__ o, long long nch) {
+__global__ void add_kernel(const h16raw* __restrict__ a, const h16raw* __restrict__ b, h16raw* __restrict__ o, long long nch) {
   GSTRIDE(i, nch) {
     float f[8], d[8];
     unpack8(*(const uint4*)(a + i * 8), f);
@@ -52,11 +57,11 @@ __global__ void add_kernel(const bfraw* __restrict__ a, const bfraw* __restrict_
     *(uint4*)(o + i * 8) = pack8(f);
   }
 }
-__global__ void cast_f2b_kernel(const float* __restrict__ in, bfraw* __restrict__ out, long long n) {
-  GSTRIDE(i, n) out[i] = f2bf(in[i]);
+__global__ void cast_f2b_kernel(const float* __restrict__ in, h16raw* __restrict__ out, long long n) {
+  GSTRIDE(i, n) out[i] = f2h(in[i]);
 }
-__global__ void cast_b2f_kernel(const bfraw* __restrict__ in, float* __restrict__ out, long long n) {
-  GSTRIDE(i, n) out[i] = bf2f(in[i]);
+__global__ void cast_b2f_kernel(const h16raw* __restrict__ in, float* __restrict__ out, long long n) {
+  GSTRIDE(i, n) out[i] = h2f(in[i]);
 }
 __global__ void fill_kernel(float* p, float v, long long n) { GSTRIDE(i, n) p[i] = v; }
 
@@ -69,13 +74,13 @@ __global__ void copy2d_kernel(const float* __restrict__ in, int ld_in, float* __
 }
 
 // out[r][c] (rows_out x ld_out, zero padded) = in[r][c] or in[c][r]
-__global__ void cast_pad_2d_kernel(const float* __restrict__ in, int rows, int cols, int ld_in, bfraw* __restrict__ out,
+__global__ void cast_pad_2d_kernel(const float* __restrict__ in, int rows, int cols, int ld_in, h16raw* __restrict__ out,
                                    int rows_out, int cols_out, int ld_out, int transpose) {
   GSTRIDE(i, (long long)rows_out * cols_out) {
     const int r = (int)(i / cols_out), c = (int)(i % cols_out);
     float v = 0.f;
     if (r < rows && c < cols) v = transpose ? in[(long long)c * ld_in + r] : in[(long long)r * ld_in + c];
-    out[(long long)r * ld_out + c] = f2bf(v);
+    out[(long long)r * ld_out + c] = f2h(v);
   }
 }
 
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256) void cast_pad_2d_multi_kernel(const CastItem* 
       if (r < it.rows_out && c < it.cols_out) {
         const float v = it.transpose ? tile[tx][ty + 8 * k] : tile[ty + 8 * k][tx];
         if (it.out_f32) ((float*)it.out)[r * it.ld_out + c] = v;
-        else ((bfraw*)it.out)[r * it.ld_out + c] = f2bf(v);
+        else ((h16raw*)it.out)[r * it.ld_out + c] = f2h(v);
       }
     }
     __syncthreads();
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void cast_pad_2d_multi_kernel(const CastItem* 
 }
 
 // w [Co][Ci][taps] -> out[row][tap][cg]; row = co (or ci when transpose_io), channel = ci (or co)
-__global__ void prep_conv_kernel(const float* __restrict__ w, int Co, int Ci, int taps, bfraw* __restrict__ out,
+__global__ void prep_conv_kernel(const float* __restrict__ w, int Co, int Ci, int taps, h16raw* __restrict__ out,
                                  int rows_out, int cg, int transpose_io, int flip, float scale) {
   GSTRIDE(i, (long long)rows_out * taps * cg) {
     const int c = (int)(i % cg);
@@ -129,7 +134,7 @@ __global__ void prep_conv_kernel(const float* __restrict__ w, int Co, int Ci, in
     const int co = transpose_io ? c : row, ci = transpose_io ? row : c;
     float v = 0.f;
     if (co < Co && ci < Ci) v = w[((long long)co * Ci + ci) * taps + tap] * scale;
-    out[i] = f2bf(v);
+    out[i] = f2h(v);
   }
 }
 __global__ void unprep_conv_kernel(const float* __restrict__ g, int Co, int Ci, int taps, int cg, float* __restrict__ dw) {
@@ -154,18 +159,18 @@ __global__ void select_taps_kernel(const uint4* __restrict__ w, int taps, int cg
 }
 
 // batched bf16 transpose through LDS: in [R][ld_in] (C cols) -> out [C][ld_out] (R cols, zero padded)
-__global__ __launch_bounds__(256) void transpose_kernel(const bfraw* __restrict__ in, long long in_bs, int ld_in,
-                                                        bfraw* __restrict__ out, long long out_bs, int ld_out, int R, int C,
+__global__ __launch_bounds__(256) void transpose_kernel(const h16raw* __restrict__ in, long long in_bs, int ld_in,
+                                                        h16raw* __restrict__ out, long long out_bs, int ld_out, int R, int C,
                                                         int inner, long long in_s1, long long out_s1, int r_pad) {
-  __shared__ bfraw tile[32][33];
+  __shared__ h16raw tile[32][33];
   const int z = blockIdx.z;
-  const bfraw* ip = in + (z / inner) * in_bs + (z % inner) * in_s1;
-  bfraw* op = out + (z / inner) * out_bs + (z % inner) * out_s1;
+  const h16raw* ip = in + (z / inner) * in_bs + (z % inner) * in_s1;
+  h16raw* op = out + (z / inner) * out_bs + (z % inner) * out_s1;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   for (int k = ty; k < 32; k += 8) {
     const int r = r0 + k, c = c0 + tx;
-    tile[k][tx] = (r < R && c < C) ? ip[(long long)r * ld_in + c] : (bfraw)0;
+    tile[k][tx] = (r < R && c < C) ? ip[(long long)r * ld_in + c] : (h16raw)0;
   }
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bfraw* __restrict_
 }
 
 // x fp32 [B][3][T][H][W] -> out bf16 [B][T][H][W][8]
-__global__ void video_norm_kernel(const float* __restrict__ x, bfraw* __restrict__ out, long long npos, long long thw,
+__global__ void video_norm_kernel(const float* __restrict__ x, h16raw* __restrict__ out, long long npos, long long thw,
                                   float m0, float m1, float m2, float i0, float i1, float i2) {
   GSTRIDE(i, npos) {
     const long long b = i / thw, p = i % thw;
@@ -186,7 +191,7 @@ __global__ void video_norm_kernel(const float* __restrict__ x, bfraw* __restrict
 }
 
 // column sums of bf16 [M][ld] -> out fp32 [N] (atomics over row slabs; out zeroed by the launcher)
-__global__ __launch_bounds__(256) void colsum_kernel(const bfraw* __restrict__ x, long long M, int N, int ld,
+__global__ __launch_bounds__(256) void colsum_kernel(const h16raw* __restrict__ x, long long M, int N, int ld,
                                                      int rows_per_blk, float* out) {
   const int cpr = (N + 7) / 8;
   const long long r0 = (long long)blockIdx.x * rows_per_blk;
@@ -213,31 +218,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bfraw* __restrict__ x
 
 extern "C" int pp_gelu_fwd(const void* x, void* y, long long n, pp_stream_t s) {
   CHK8(n, "pp_gelu_fwd");
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)x, (bfraw*)y, n / 8);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const h16raw*)x, (h16raw*)y, n / 8);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
 extern "C" int pp_gelu_bwd(const void* dy, const void* x, void* dx, long long n, pp_stream_t s) {
   CHK8(n, "pp_gelu_bwd");
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)dy, (const bfraw*)x, (bfraw*)dx, n / 8);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const h16raw*)dy, (const h16raw*)x, (h16raw*)dx, n / 8);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
 extern "C" int pp_add_bf16(const void* a, const void* b, void* out, long long n, pp_stream_t s) {
   CHK8(n, "pp_add_bf16");
-  hipLaunchKernelGGL(add_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)a, (const bfraw*)b, (bfraw*)out, n / 8);
+  hipLaunchKernelGGL(add_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const h16raw*)a, (const h16raw*)b, (h16raw*)out, n / 8);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
 extern "C" int pp_cast_f32_to_bf16(const float* in, void* out, long long n, pp_stream_t s) {
   PP_CHECK_ARG(n > 0, "pp_cast_f32_to_bf16: n");
-  hipLaunchKernelGGL(cast_f2b_kernel, dim3(sgrid(n)), dim3(256), 0, S_, in, (bfraw*)out, n);
+  hipLaunchKernelGGL(cast_f2b_kernel, dim3(sgrid(n)), dim3(256), 0, S_, in, (h16raw*)out, n);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
 extern "C" int pp_cast_bf16_to_f32(const void* in, float* out, long long n, pp_stream_t s) {
   PP_CHECK_ARG(n > 0, "pp_cast_bf16_to_f32: n");
-  hipLaunchKernelGGL(cast_b2f_kernel, dim3(sgrid(n)), dim3(256), 0, S_, (const bfraw*)in, out, n);
+  hipLaunchKernelGGL(cast_b2f_kernel, dim3(sgrid(n)), dim3(256), 0, S_, (const h16raw*)in, out, n);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -257,7 +262,7 @@ extern "C" int pp_cast_pad_2d(const float* in, int rows, int cols, int ld_in, vo
                               int ld_out, int transpose, pp_stream_t s) {
   PP_CHECK_ARG(rows > 0 && cols > 0 && rows_out >= rows && cols_out >= cols && ld_out >= cols_out, "pp_cast_pad_2d: sizes");
   hipLaunchKernelGGL(cast_pad_2d_kernel, dim3(sgrid((long long)rows_out * cols_out)), dim3(256), 0, S_, in, rows, cols, ld_in,
-                     (bfraw*)out, rows_out, cols_out, ld_out, transpose);
+                     (h16raw*)out, rows_out, cols_out, ld_out, transpose);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -273,7 +278,7 @@ extern "C" int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, voi
   PP_CHECK_ARG(Co > 0 && Ci > 0 && taps > 0 && rows_out > 0 && cg > 0 && cg % 8 == 0, "pp_prep_conv_weight: sizes");
   PP_CHECK_ARG(transpose_io ? (rows_out >= Ci && cg >= Co) : (rows_out >= Co && cg >= Ci), "pp_prep_conv_weight: pad too small");
   hipLaunchKernelGGL(prep_conv_kernel, dim3(sgrid((long long)rows_out * taps * cg)), dim3(256), 0, S_, w, Co, Ci, taps,
-                     (bfraw*)out, rows_out, cg, transpose_io, flip, scale);
+                     (h16raw*)out, rows_out, cg, transpose_io, flip, scale);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -301,7 +306,7 @@ extern "C" int pp_transpose_bf16(const void* in, long long in_bs, int ld_in, voi
   PP_CHECK_ARG(nb > 0 && R > 0 && C > 0 && r_pad >= R && ld_out >= r_pad && ld_in >= C, "pp_transpose_bf16: sizes");
   if (inner <= 0) inner = 1;
   dim3 grid((C + 31) / 32, (r_pad + 31) / 32, nb);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, S_, (const bfraw*)in, in_bs, ld_in, (bfraw*)out, out_bs, ld_out, R, C,
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, S_, (const h16raw*)in, in_bs, ld_in, (h16raw*)out, out_bs, ld_out, R, C,
                      inner, in_s1, out_s1, r_pad);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -310,7 +315,7 @@ extern "C" int pp_video_normalize_ndhwc(const float* x, void* out, int B, int T,
                                         const float* std3, pp_stream_t s) {
   PP_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0 && mean3 && std3, "pp_video_normalize_ndhwc: sizes");
   const long long thw = (long long)T * H * W;
-  hipLaunchKernelGGL(video_norm_kernel, dim3(sgrid(B * thw)), dim3(256), 0, S_, x, (bfraw*)out, B * thw, thw, mean3[0],
+  hipLaunchKernelGGL(video_norm_kernel, dim3(sgrid(B * thw)), dim3(256), 0, S_, x, (h16raw*)out, B * thw, thw, mean3[0],
                      mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -322,7 +327,7 @@ extern "C" int pp_colsum_bf16(const void* x, long long M, int N, int ld, float* 
   int nblk = (int)((M + 63) / 64);
   if (nblk > 1024) nblk = 1024;
   const int rows_per_blk = (int)((M + nblk - 1) / nblk);
-  hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, S_, (const bfraw*)x, M, N, ld, rows_per_blk, out);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, S_, (const h16raw*)x, M, N, ld, rows_per_blk, out);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -333,7 +338,7 @@ __device__ __forceinline__ void max8(float* m, const float* v) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], v[q]);
 }
-__global__ void maxpool_fwd_kernel(const bfraw* __restrict__ x, bfraw* __restrict__ y, int N, int H, int W, int Ho, int Wo,
+__global__ void maxpool_fwd_kernel(const h16raw* __restrict__ x, h16raw* __restrict__ y, int N, int H, int W, int Ho, int Wo,
                                    int cpr) {
   GSTRIDE(i, (long long)N * Ho * Wo * cpr) {
     const int c = (int)(i % cpr);
@@ -357,7 +362,7 @@ __global__ void maxpool_fwd_kernel(const bfraw* __restrict__ x, bfraw* __restric
   }
 }
 // gather form of the backward: an input position receives dY of every window whose FIRST maximum it is
-__global__ void maxpool_bwd_kernel(const bfraw* __restrict__ x, const bfraw* __restrict__ dy, bfraw* __restrict__ dx, int N,
+__global__ void maxpool_bwd_kernel(const h16raw* __restrict__ x, const h16raw* __restrict__ dy, h16raw* __restrict__ dx, int N,
                                    int H, int W, int Ho, int Wo, int cpr) {
   GSTRIDE(i, (long long)N * H * W * cpr) {
     const int c = (int)(i % cpr);
@@ -401,16 +406,16 @@ __global__ void maxpool_bwd_kernel(const bfraw* __restrict__ x, const bfraw* __r
 extern "C" int pp_maxpool3x3s2_fwd(const void* x, void* y, int N, int H, int W, int Cp, pp_stream_t s) {
   PP_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "pp_maxpool3x3s2_fwd: sizes");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(sgrid((long long)N * Ho * Wo * (Cp / 8))), dim3(256), 0, S_, (const bfraw*)x,
-                     (bfraw*)y, N, H, W, Ho, Wo, Cp / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(sgrid((long long)N * Ho * Wo * (Cp / 8))), dim3(256), 0, S_, (const h16raw*)x,
+                     (h16raw*)y, N, H, W, Ho, Wo, Cp / 8);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
 extern "C" int pp_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int Cp, pp_stream_t s) {
   PP_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "pp_maxpool3x3s2_bwd: sizes");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(sgrid((long long)N * H * W * (Cp / 8))), dim3(256), 0, S_, (const bfraw*)x,
-                     (const bfraw*)dy, (bfraw*)dx, N, H, W, Ho, Wo, Cp / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(sgrid((long long)N * H * W * (Cp / 8))), dim3(256), 0, S_, (const h16raw*)x,
+                     (const h16raw*)dy, (h16raw*)dx, N, H, W, Ho, Wo, Cp / 8);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -419,7 +424,7 @@ extern "C" int pp_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int 
 // Counter-based mask: element i is kept iff hash16(seed, i) >= p * 65536; the same (seed, i) regenerates the
 // mask in the backward pass, so no mask tensor is stored.  y = keep ? x / (1 - p) : 0  (+ res).
 namespace {
-__global__ void dropout_bf16_kernel(const bfraw* __restrict__ x, const bfraw* __restrict__ res, bfraw* __restrict__ y, long long nch,
+__global__ void dropout_bf16_kernel(const h16raw* __restrict__ x, const h16raw* __restrict__ res, h16raw* __restrict__ y, long long nch,
                                     uint32_t thr, float scale, uint32_t seed) {
   GSTRIDE(i, nch) {
     float f[8], r[8];
@@ -437,7 +442,7 @@ __global__ void dropout_bf16_kernel(const bfraw* __restrict__ x, const bfraw* __
   }
 }
 // dx = dropout_bwd(dy) * gelu'(x) in one pass (the feed-forward's intermediate dropout sits right behind its GELU)
-__global__ void gelu_bwd_dropout_kernel(const bfraw* __restrict__ dy, const bfraw* __restrict__ x, bfraw* __restrict__ dx,
+__global__ void gelu_bwd_dropout_kernel(const h16raw* __restrict__ dy, const h16raw* __restrict__ x, h16raw* __restrict__ dx,
                                         long long nch, uint32_t thr, float scale, uint32_t seed) {
   GSTRIDE(i, nch) {
     float f[8], d[8];
@@ -464,7 +469,7 @@ __global__ void dropout_f32_kernel(const float* __restrict__ x, float* __restric
 extern "C" int pp_dropout_bf16(const void* x, const void* res, void* y, long long n, float p, unsigned seed, pp_stream_t s) {
   CHK8(n, "pp_dropout_bf16");
   PP_CHECK_ARG(p >= 0.f && p < 1.f, "pp_dropout_bf16: p=%f", (double)p);
-  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)x, (const bfraw*)res, (bfraw*)y, n / 8,
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const h16raw*)x, (const h16raw*)res, (h16raw*)y, n / 8,
                      (uint32_t)(p * 65536.f + 0.5f), 1.f / (1.f - p), seed);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -472,8 +477,8 @@ extern "C" int pp_dropout_bf16(const void* x, const void* res, void* y, long lon
 extern "C" int pp_gelu_bwd_dropout(const void* dy, const void* x, void* dx, long long n, float p, unsigned seed, pp_stream_t s) {
   CHK8(n, "pp_gelu_bwd_dropout");
   PP_CHECK_ARG(p >= 0.f && p < 1.f, "pp_gelu_bwd_dropout: p=%f", (double)p);
-  hipLaunchKernelGGL(gelu_bwd_dropout_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const bfraw*)dy, (const bfraw*)x,
-                     (bfraw*)dx, n / 8, (uint32_t)(p * 65536.f + 0.5f), 1.f / (1.f - p), seed);
+  hipLaunchKernelGGL(gelu_bwd_dropout_kernel, dim3(sgrid(n / 8)), dim3(256), 0, S_, (const h16raw*)dy, (const h16raw*)x,
+                     (h16raw*)dx, n / 8, (uint32_t)(p * 65536.f + 0.5f), 1.f / (1.f - p), seed);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -123,18 +123,18 @@ int colsum_f32(hipStream_t s, const float* X, int M, int N, int ld, float* out) 
 }
 
 // ---- spatial mean over HW (VideoAttention.spatial_avg) -----------------------------------------
-__global__ void spatial_mean_fwd_kernel(const bfraw* __restrict__ x, float* __restrict__ out, int HW, int C, int Cp) {
+__global__ void spatial_mean_fwd_kernel(const h16raw* __restrict__ x, float* __restrict__ out, int HW, int C, int Cp) {
   const long long bt = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += bf2f(x[(bt * HW + p) * Cp + c]);
+    for (int p = 0; p < HW; ++p) s += h2f(x[(bt * HW + p) * Cp + c]);
     out[bt * C + c] = s / HW;
   }
 }
-__global__ void spatial_mean_bwd_kernel(const float* __restrict__ dout, bfraw* __restrict__ dx, int HW, int C, int Cp) {
+__global__ void spatial_mean_bwd_kernel(const float* __restrict__ dout, h16raw* __restrict__ dx, int HW, int C, int Cp) {
   const long long bt = blockIdx.x;
   for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
-    const bfraw v = f2bf(c < C ? dout[bt * C + c] / HW : 0.f);
+    const h16raw v = f2h(c < C ? dout[bt * C + c] / HW : 0.f);
     for (int p = 0; p < HW; ++p) dx[(bt * HW + p) * Cp + c] = v;
   }
 }
@@ -395,13 +395,13 @@ __global__ void scale_f32_kernel(float* x, const float* sc, long long n) {
 
 extern "C" int pp_spatial_mean_fwd(const void* x, float* out, int B, int T, int HW, int C, int Cp, pp_stream_t s) {
   PP_CHECK_ARG(B > 0 && T > 0 && HW > 0 && C > 0 && Cp >= C, "pp_spatial_mean_fwd: sizes");
-  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(B * T), dim3(256), 0, S_, (const bfraw*)x, out, HW, C, Cp);
+  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(B * T), dim3(256), 0, S_, (const h16raw*)x, out, HW, C, Cp);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
 extern "C" int pp_spatial_mean_bwd(const float* dout, void* dx, int B, int T, int HW, int C, int Cp, pp_stream_t s) {
   PP_CHECK_ARG(B > 0 && T > 0 && HW > 0 && C > 0 && Cp >= C, "pp_spatial_mean_bwd: sizes");
-  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(B * T), dim3(256), 0, S_, dout, (bfraw*)dx, HW, C, Cp);
+  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(B * T), dim3(256), 0, S_, dout, (h16raw*)dx, HW, C, Cp);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

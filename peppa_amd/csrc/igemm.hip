@@ -102,9 +102,9 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
   constexpr int NAI = 4;                       // A chunks per thread and K-step
   constexpr int NBI = (BN * 8 + NT - 1) / NT;  // B chunks per thread and K-step
   // one LDS object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM + (MODE != PP_DENSE ? 1024 : 0)];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM + (MODE != PP_DENSE ? 2048 : 0)];
   int* const lut = (int*)(smem + SMEM);            // packed (dt, dh, dw) per tap
-  int* const lut_off = (int*)(smem + SMEM + 512);  // byte offset of the tap inside the source tensor (linear part)
+  int* const lut_off = (int*)(smem + SMEM + 1024);  // byte offset of the tap inside the source tensor (linear part)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
   const int z = blockIdx.z;
   const int zo = z / p.inner, zi = z % p.inner;
 
-  const bfraw* A = (const bfraw*)p.A + zo * p.a_s0 + zi * p.a_s1;
-  const bfraw* Bt = (const bfraw*)p.Bt + zo * p.b_s0 + zi * p.b_s1;
+  const h16raw* A = (const h16raw*)p.A + zo * p.a_s0 + zi * p.a_s1;
+  const h16raw* Bt = (const h16raw*)p.Bt + zo * p.b_s0 + zi * p.b_s1;
   const long long c_off = zo * p.c_s0 + zi * p.c_s1;
   const float* __restrict__ bias = p.bias ? p.bias + zo * p.bias_s0 + zi * p.bias_s1 : nullptr;
   // raw buffer descriptors (wave-uniform): an offset of OOB is out of range and loads zeros, which
@@ -140,18 +140,18 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
   const pp_gather& g = p.g;
   const int ntaps = g.kt * g.kh * g.kw;
   if (MODE != PP_DENSE) {
-    if (tid < 128) {
+    for (int tp = tid; tp < 256; tp += NT) {   // up to 256 taps (r3d_18's (3,7,7) stem has 147)
       int e = 0, o = 0;
-      if (tid < ntaps) {
-        const int dw = tid % g.kw;
-        const int t2 = tid / g.kw;
+      if (tp < ntaps) {
+        const int dw = tp % g.kw;
+        const int t2 = tp / g.kw;
         const int dh = t2 % g.kh;
         const int dt = t2 / g.kh;
         e = dt | (dh << 8) | (dw << 16);
         o = ((dt * g.Gh + dh) * g.Gw + dw) * g.cstride * 2;
       }
-      lut[tid] = e;
-      lut_off[tid] = o;
+      lut[tp] = e;
+      lut_off[tp] = o;
     }
     __syncthreads();
   }
@@ -222,8 +222,8 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
       for (int i = 0; i < NAI; ++i) offA[i] = (k_ok && ri[i].base != OOB) ? ri[i].base + (unsigned)kcur * 2u : OOB;
     } else {
       const bool tap_ok = tap < ntaps;
-      const int e = lut[tap & 127];
-      const int toff = lut_off[tap & 127] + cch * 2;
+      const int e = lut[tap & 255];
+      const int toff = lut_off[tap & 255] + cch * 2;
       const int dt = e & 0xff, dh = (e >> 8) & 0xff, dw = (e >> 16) & 0xff;
 #pragma unroll
       for (int i = 0; i < NAI; ++i) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
           const int nt = r.bt - dt, nh = r.bh - dh, nw = r.bw - dw;
           if (unit_stride) {
             ok = tap_ok && (unsigned)nt < (unsigned)g.Gt && (unsigned)nh < (unsigned)g.Gh && (unsigned)nw < (unsigned)g.Gw;
-            off = r.base - (unsigned)lut_off[tap & 127] + (unsigned)cch * 2u;
+            off = r.base - (unsigned)lut_off[tap & 255] + (unsigned)cch * 2u;
           } else {
             const int gt = nt >> sft, gh = nh >> sfh, gw = nw >> sfw;
             ok = tap_ok && (((nt & sft) | (nh & sfh) | (nw & sfw)) == 0) && nt >= 0 && nh >= 0 && nw >= 0 &&
@@ -311,14 +311,14 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int fsw = ((ks * 4 + fq) ^ swz(fr)) << 4;
-      bf16x8 af[2];
+      h16x8 af[2];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) af[mt] = *(const bf16x8*)(buf + (wave * 32 + mt * 16 + fr) * 128 + fsw);
+      for (int mt = 0; mt < 2; ++mt) af[mt] = *(const h16x8*)(buf + (wave * 32 + mt * 16 + fr) * 128 + fsw);
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        const bf16x8 bfm = *(const bf16x8*)(buf + A_BYTES + (j * 16 + fr) * 128 + fsw);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfm, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfm, acc[1][j], 0, 0, 0);
+        const h16x8 bfm = *(const h16x8*)(buf + A_BYTES + (j * 16 + fr) * 128 + fsw);
+        acc[0][j] = PP_MFMA16(af[0], bfm, acc[0][j], 0, 0, 0);
+        acc[1][j] = PP_MFMA16(af[1], bfm, acc[1][j], 0, 0, 0);
       }
     }
   };
@@ -380,13 +380,13 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
   // The slab is wave-private, so LDS program order (+ lgkmcnt waits) is the only synchronisation needed.
   unsigned char* stg = ebuf + wave * 16 * STG_STRIDE;
   unsigned char* stg_w = stg + (fq * 4) * STG_STRIDE + fr * 2;
-  auto write_out = [&](bfraw* Cout, const bfraw* residual) __attribute__((always_inline)) {
+  auto write_out = [&](h16raw* Cout, const h16raw* residual) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *(bfraw*)(stg_w + r * STG_STRIDE + j * 32) = f2bf(acc[mt][j][r]);
+        for (int r = 0; r < 4; ++r) *(h16raw*)(stg_w + r * STG_STRIDE + j * 32) = f2h(acc[mt][j][r]);
       if (RING) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a fence would also drain the LDS-DMAs in flight)
       else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
             const int rt = (int)t2 - n * g.Rt;
             orow = (((long long)n * p.Ot + rt * p.os_t + p.oo_t) * p.Oh + rh * p.os_h + p.oo_h) * p.Ow + rw * p.os_w + p.oo_w;
           }
-          if (FULL && drop_thr && Cout == (bfraw*)p.C) {   // (not the pre-activation copy)
+          if (FULL && drop_thr && Cout == (h16raw*)p.C) {   // (not the pre-activation copy)
             float x[8];
             bool keep[8];
             unpack8(v, x);
@@ -445,12 +445,12 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
     }
   };
   if (FULL) {
-    if (p.Cpre) write_out((bfraw*)p.Cpre, nullptr);
+    if (p.Cpre) write_out((h16raw*)p.Cpre, nullptr);
     activate();
-    write_out((bfraw*)p.C, (const bfraw*)p.residual);
+    write_out((h16raw*)p.C, (const h16raw*)p.residual);
     return;
   }
-  write_out((bfraw*)p.C, nullptr);
+  write_out((h16raw*)p.C, nullptr);
   if (p.colstats) {
     // per-column sum / sum of squares over this block's 128 rows (fp32 accumulators), deterministic:
     // in-lane over 8 rows, xor-shuffles over the 4 row groups, LDS over the 4 waves
@@ -677,8 +677,8 @@ int pp_validate_gather(const pp_gather& g, int K, const char* who) {
   }
   PP_CHECK_ARG(g.mode == PP_CONV_FWD || g.mode == PP_CONV_DGRAD, "%s: bad gather mode %d", who, g.mode);
   PP_CHECK_ARG(g.Rt > 0 && g.Rh > 0 && g.Rw > 0 && g.Gt > 0 && g.Gh > 0 && g.Gw > 0, "%s: bad extents", who);
-  PP_CHECK_ARG(g.kt > 0 && g.kh > 0 && g.kw > 0 && g.kt * g.kh * g.kw <= 128 && g.kt < 256 && g.kh < 256 &&
-                   g.kw < 256, "%s: taps %dx%dx%d unsupported (<=128 total)", who, g.kt, g.kh, g.kw);
+  PP_CHECK_ARG(g.kt > 0 && g.kh > 0 && g.kw > 0 && g.kt * g.kh * g.kw <= 256 && g.kt < 256 && g.kh < 256 &&
+                   g.kw < 256, "%s: taps %dx%dx%d unsupported (<=256 total)", who, g.kt, g.kh, g.kw);
   PP_CHECK_ARG(g.cg > 0 && g.cg % 8 == 0 && g.cstride % 8 == 0 && g.cstride >= g.cg,
                "%s: cg=%d cstride=%d must be multiples of 8", who, g.cg, g.cstride);
   PP_CHECK_ARG(K == g.kt * g.kh * g.kw * g.cg, "%s: K=%d != taps*cg=%d", who, K, g.kt * g.kh * g.kw * g.cg);

@@ -65,10 +65,10 @@ struct WinGeom {
 };
 
 struct WinArgs {
-  const bfraw* A;
-  const bfraw* Bt;
-  bfraw* C;
-  const bfraw* residual;
+  const h16raw* A;
+  const h16raw* Bt;
+  h16raw* C;
+  const h16raw* residual;
   float* colstats;
   int N, b_rows, ldb, ldc, ldr, ldstat;
 };
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     // every fragment of the K-step is requested before the first MFMA: written as "load one weight fragment, use it"
     // hipcc keeps ONE fragment register and waits lgkmcnt(0) before every MFMA pair, i.e. one exposed LDS round trip
     // (~100 cycles) per 32 cycles of matrix work
-    bf16x8 af[2][MT], bfm[2][WN];
+    h16x8 af[2][MT], bfm[2][WN];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int tap = tapA[ks], c = cA[ks];
@@ -270,11 +270,11 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         const int col = CC == 64 ? (((c >> 3) ^ swz(wrow)) << 4) : c * 2;
         const bool ok = ((vmask[mt] >> tap) & 1u) != 0u;    // (tap >= NTAP, the K tail, has no bit set)
         const unsigned char* a = ok ? win + wrow * XS + col : zrow + fr * 16;
-        af[ks][mt] = *(const bf16x8*)a;
+        af[ks][mt] = *(const h16x8*)a;
       }
       const int fsw = ((ks * 4 + fq) ^ swz(fr)) << 4;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bfm[ks][j] = *(const bf16x8*)(bslot + (j * 16 + fr) * 128 + fsw);
+      for (int j = 0; j < WN; ++j) bfm[ks][j] = *(const h16x8*)(bslot + (j * 16 + fr) * 128 + fsw);
       cA[ks] += BK;
       while (cA[ks] >= CC) { cA[ks] -= CC; ++tapA[ks]; }
     }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][mt], bfm[ks][j], acc[mt][j], 0, 0, 0);
+          acc[mt][j] = PP_MFMA16(af[ks][mt], bfm[ks][j], acc[mt][j], 0, 0, 0);
   };
 
   // ---- epilogue (plain bf16 store, optional residual add, optional BatchNorm column statistics); igemm.hip's ------
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *(bfraw*)(stg_w + r * STG_STRIDE + j * 32) = f2bf(acc[mt][j][r]);
+        for (int r = 0; r < 4; ++r) *(h16raw*)(stg_w + r * STG_STRIDE + j * 32) = f2h(acc[mt][j][r]);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -496,7 +496,7 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   g.nblk = g.HW / g.PB;
   g.dBlk = make_fastdiv((uint32_t)(g.nblk > 0 ? g.nblk : 1));
   WinArgs a;
-  a.A = (const bfraw*)d.A; a.Bt = (const bfraw*)d.Bt; a.C = (bfraw*)d.C; a.residual = (const bfraw*)d.residual;
+  a.A = (const h16raw*)d.A; a.Bt = (const h16raw*)d.Bt; a.C = (h16raw*)d.C; a.residual = (const h16raw*)d.residual;
   a.colstats = d.colstats;
   a.N = d.N; a.b_rows = d.b_rows; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr; a.ldstat = d.ldstat;
   const int nblk_n = (d.N + BN - 1) / BN;

@@ -8,8 +8,8 @@ namespace {
 
 constexpr int LN_MAXC = 2;  // chunks (of 8) per lane -> D <= 1024
 
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const bfraw* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float eps, bfraw* __restrict__ y,
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const h16raw* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, h16raw* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int D) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -51,9 +51,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bfraw* __restrict__ x
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bfraw* __restrict__ dy, const bfraw* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const h16raw* __restrict__ dy, const h16raw* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, bfraw* __restrict__ dx,
+                                                     const float* __restrict__ rstd, h16raw* __restrict__ dx,
                                                      float* dgamma, float* dbeta, int rows, int D, int rows_per_wave,
                                                      float* __restrict__ ws) {
   const int lane = threadIdx.x & 63;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void ln_bwd_partials_kernel(const float* __res
 
 constexpr int SM_MAXC = 4;  // columns per lane -> T <= 256
 
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, int lds, bfraw* __restrict__ P, int ldp,
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, int lds, h16raw* __restrict__ P, int ldp,
                                                           long long rows, int T, float scale) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -199,12 +199,12 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 #pragma unroll
   for (int c = 0; c < SM_MAXC; ++c) {
     const int j = lane + 64 * c;
-    if (j < ldp) P[row * ldp + j] = f2bf(v[c] * inv);
+    if (j < ldp) P[row * ldp + j] = f2h(v[c] * inv);
   }
 }
 
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dP, int lds, const bfraw* __restrict__ P,
-                                                          int ldp, bfraw* __restrict__ dS, long long rows, int T, float scale) {
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dP, int lds, const h16raw* __restrict__ P,
+                                                          int ldp, h16raw* __restrict__ dS, long long rows, int T, float scale) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 #pragma unroll
   for (int c = 0; c < SM_MAXC; ++c) {
     const int j = lane + 64 * c;
-    p[c] = j < T ? bf2f(P[row * ldp + j]) : 0.f;
+    p[c] = j < T ? h2f(P[row * ldp + j]) : 0.f;
     d[c] = j < T ? dP[row * lds + j] : 0.f;
     dot += p[c] * d[c];
   }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 #pragma unroll
   for (int c = 0; c < SM_MAXC; ++c) {
     const int j = lane + 64 * c;
-    if (j < ldp) dS[row * ldp + j] = f2bf(scale * p[c] * (d[c] - dot));
+    if (j < ldp) dS[row * ldp + j] = f2h(scale * p[c] * (d[c] - dot));
   }
 }
 
@@ -282,7 +282,7 @@ __device__ __forceinline__ GN0 gn0_load(const float* stats, int b, int c, int T0
 }
 
 __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* wave, int L, int T0, const float* w, const float* stats,
-                                                          const float* gamma, const float* beta, float eps, bfraw* out) {
+                                                          const float* gamma, const float* beta, float eps, h16raw* out) {
   __shared__ float xs[(TT0 - 1) * S0 + K0];
   const int c = threadIdx.x * 2;
   const GN0 g = gn0_load(stats, blockIdx.y, c, T0, eps);
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* wave, int
 
 __global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* wave, int L, int T0, const float* w,
                                                                const float* stats, const float* gamma, const float* beta,
-                                                               float eps, const bfraw* dout, float* red) {
+                                                               float eps, const h16raw* dout, float* red) {
   __shared__ float xs[(TT0 - 1) * S0 + K0];
   const int c = threadIdx.x * 2;
   const GN0 g = gn0_load(stats, blockIdx.y, c, T0, eps);
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* wave
   conv0_tile(wave, L, T0, w, xs, [&](int b, int tg, int, int cc, float y0, float y1) {
     const float xh0 = (y0 - g.mu0) * g.rs0, xh1 = (y1 - g.mu1) * g.rs1;
     const uint32_t dv = *(const uint32_t*)(dout + ((long long)b * T0 + tg) * C0 + cc);
-    const float du0 = bf2f((bfraw)(dv & 0xffff)) * gelu_grad_f(xh0 * g0 + b0);
-    const float du1 = bf2f((bfraw)(dv >> 16)) * gelu_grad_f(xh1 * g1 + b1);
+    const float du0 = h2f((h16raw)(dv & 0xffff)) * gelu_grad_f(xh0 * g0 + b0);
+    const float du1 = h2f((h16raw)(dv >> 16)) * gelu_grad_f(xh1 * g1 + b1);
     r00 += du0; r01 += du0 * xh0; r10 += du1; r11 += du1 * xh1;
   });
   float* rp = red + ((long long)blockIdx.y * C0 + c) * 2;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* wave
 
 __global__ __launch_bounds__(256) void conv0_bwd_apply_kernel(const float* wave, int L, int T0, const float* w,
                                                               const float* stats, const float* gamma, const float* beta,
-                                                              float eps, const bfraw* dout, const float* red, float* dw,
+                                                              float eps, const h16raw* dout, const float* red, float* dw,
                                                               float* dgamma, float* dbeta) {
   __shared__ float xs[(TT0 - 1) * S0 + K0];
   const int c = threadIdx.x * 2;
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_apply_kernel(const float* wave,
   conv0_tile(wave, L, T0, w, xs, [&](int b, int tg, int tl, int cc, float y0, float y1) {
     const float xh0 = (y0 - g.mu0) * g.rs0, xh1 = (y1 - g.mu1) * g.rs1;
     const uint32_t dv = *(const uint32_t*)(dout + ((long long)b * T0 + tg) * C0 + cc);
-    const float du0 = bf2f((bfraw)(dv & 0xffff)) * gelu_grad_f(xh0 * g0 + b0);
-    const float du1 = bf2f((bfraw)(dv >> 16)) * gelu_grad_f(xh1 * g1 + b1);
+    const float du0 = h2f((h16raw)(dv & 0xffff)) * gelu_grad_f(xh0 * g0 + b0);
+    const float du1 = h2f((h16raw)(dv >> 16)) * gelu_grad_f(xh1 * g1 + b1);
     const float dy0 = g.rs0 * g0 * (du0 - m00 - xh0 * m01), dy1 = g.rs1 * g1 * (du1 - m10 - xh1 * m11);
 #pragma unroll
     for (int k = 0; k < K0; ++k) {
@@ -360,13 +360,13 @@ __global__ void wn_sqrt_kernel(float* n, int Kk) {
   if (k < Kk) n[k] = sqrtf(n[k]);
 }
 __global__ void wn_apply_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ norm,
-                                int Co, int Ci, int Kk, bfraw* __restrict__ out) {
+                                int Co, int Ci, int Kk, h16raw* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)Co * Kk * Ci;
        i += (long long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Ci);
     const long long t = i / Ci;
     const int k = (int)(t % Kk), co = (int)(t / Kk);
-    out[i] = f2bf(v[((long long)co * Ci + ci) * Kk + k] * g[k] / norm[k]);
+    out[i] = f2h(v[((long long)co * Ci + ci) * Kk + k] * g[k] / norm[k]);
   }
 }
 __global__ void wn_bwd_reduce_kernel(const float* __restrict__ dwt, const float* __restrict__ v, int Co, int Ci, int Kk,
@@ -405,7 +405,7 @@ __global__ void wn_bwd_apply_kernel(const float* __restrict__ dwt, const float* 
 extern "C" int pp_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
                                 float* rstd, int rows, int D, pp_stream_t s) {
   PP_CHECK_ARG(rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXC, "pp_layernorm_fwd: D=%d unsupported", D);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, S_, (const bfraw*)x, gamma, beta, eps, (bfraw*)y, mean,
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, S_, (const h16raw*)x, gamma, beta, eps, (h16raw*)y, mean,
                      rstd, rows, D);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -423,8 +423,8 @@ extern "C" int pp_layernorm_bwd(const void* dy, const void* x, const float* gamm
   const int rows_per_wave = (rows + waves - 1) / waves;
   waves = (rows + rows_per_wave - 1) / rows_per_wave;
   const int nblk = (waves + 3) / 4;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, S_, (const bfraw*)dy, (const bfraw*)x, gamma, mean,
-                     rstd, (bfraw*)dx, dgamma, dbeta, rows, D, rows_per_wave, ws);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, S_, (const h16raw*)dy, (const h16raw*)x, gamma, mean,
+                     rstd, (h16raw*)dx, dgamma, dbeta, rows, D, rows_per_wave, ws);
   if (ws) hipLaunchKernelGGL(ln_bwd_partials_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, S_, ws, nblk, D, dgamma, dbeta);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -432,7 +432,7 @@ extern "C" int pp_layernorm_bwd(const void* dy, const void* x, const float* gamm
 extern "C" int pp_softmax_fwd(const float* S, int lds, void* P, int ldp, int nb, int T, float scale, pp_stream_t s) {
   PP_CHECK_ARG(nb > 0 && T > 0 && T <= 64 * SM_MAXC && ldp >= T && ldp <= 64 * SM_MAXC && lds >= T, "pp_softmax_fwd: T=%d ldp=%d unsupported", T, ldp);
   const long long rows = (long long)nb * T;
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_, S, lds, (bfraw*)P, ldp, rows, T, scale);
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_, S, lds, (h16raw*)P, ldp, rows, T, scale);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -440,8 +440,8 @@ extern "C" int pp_softmax_bwd(const float* dP, int lds, const void* P, int ldp, 
                               pp_stream_t s) {
   PP_CHECK_ARG(nb > 0 && T > 0 && T <= 64 * SM_MAXC && ldp >= T && ldp <= 64 * SM_MAXC && lds >= T, "pp_softmax_bwd: T=%d ldp=%d unsupported", T, ldp);
   const long long rows = (long long)nb * T;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_, dP, lds, (const bfraw*)P, ldp,
-                     (bfraw*)dS, rows, T, scale);
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_, dP, lds, (const h16raw*)P, ldp,
+                     (h16raw*)dS, rows, T, scale);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -467,7 +467,7 @@ extern "C" int pp_conv0_apply(const float* wave, int B, int L, int T0, const flo
                               const float* beta, float eps, void* out, pp_stream_t s) {
   if (int rc = conv0_check(B, L, T0, "pp_conv0_apply")) return rc;
   hipLaunchKernelGGL(conv0_apply_kernel, dim3((T0 + TT0 - 1) / TT0, B), dim3(256), 0, S_, wave, L, T0, w, stats, gamma, beta, eps,
-                     (bfraw*)out);
+                     (h16raw*)out);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -476,7 +476,7 @@ extern "C" int pp_conv0_bwd_reduce(const float* wave, int B, int L, int T0, cons
                                    pp_stream_t s) {
   if (int rc = conv0_check(B, L, T0, "pp_conv0_bwd_reduce")) return rc;
   hipLaunchKernelGGL(conv0_bwd_reduce_kernel, dim3(conv0_red_blocks(T0, B), B), dim3(256), 0, S_, wave, L, T0, w, stats, gamma, beta,
-                     eps, (const bfraw*)dout, red);
+                     eps, (const h16raw*)dout, red);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -485,7 +485,7 @@ extern "C" int pp_conv0_bwd_apply(const float* wave, int B, int L, int T0, const
                                   float* dw, float* dgamma, float* dbeta, pp_stream_t s) {
   if (int rc = conv0_check(B, L, T0, "pp_conv0_bwd_apply")) return rc;
   hipLaunchKernelGGL(conv0_bwd_apply_kernel, dim3(conv0_red_blocks(T0, B), B), dim3(256), 0, S_, wave, L, T0, w, stats, gamma, beta,
-                     eps, (const bfraw*)dout, red, dw, dgamma, dbeta);
+                     eps, (const h16raw*)dout, red, dw, dgamma, dbeta);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -500,7 +500,7 @@ extern "C" int pp_weightnorm_fwd(const float* v, const float* g, int Co, int Ci,
   hipLaunchKernelGGL(wn_sqrt_kernel, dim3((Kk + 255) / 256), dim3(256), 0, S_, norm, Kk);
   const long long n = rows * Kk;
   hipLaunchKernelGGL(wn_apply_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, S_, v, g,
-                     norm, Co, Ci, Kk, (bfraw*)out);
+                     norm, Co, Ci, Kk, (h16raw*)out);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

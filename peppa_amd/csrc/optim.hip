@@ -92,7 +92,74 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const pp_tensor_list tl, 
   }
 }
 
+// g *= inv_scale; found_inf = 1 on any non-finite element (torch._amp_foreach_non_finite_check_and_unscale_)
+__global__ __launch_bounds__(256) void unscale_check_kernel(const pp_tensor_list tl, const int* __restrict__ chunk_tensor,
+                                                            const long long* __restrict__ chunk_off, int chunk,
+                                                            const float* __restrict__ inv_scale, float* found_inf) {
+  const int t = chunk_tensor[blockIdx.x];
+  const long long off = chunk_off[blockIdx.x];
+  const long long n = tl.numel[t];
+  float* g = (float*)tl.g[t];
+  const long long end = off + chunk < n ? off + chunk : n;
+  const float k = inv_scale[0];
+  bool bad = false;
+  long long done = off;
+  if (aligned16(g, g, g, g)) {
+    const long long nvec = (end - off) >> 2;
+    float4* g4 = (float4*)(g + off);
+    for (long long i = threadIdx.x; i < nvec; i += 256) {
+      float4 v = g4[i];
+      bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+      v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+      g4[i] = v;
+    }
+    done = off + (nvec << 2);
+  }
+  for (long long i = done + threadIdx.x; i < end; i += 256) {
+    const float v = g[i];
+    bad |= !isfinite(v);
+    g[i] = v * k;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.f;
+}
+
+__global__ void amp_update_scale_kernel(float* scale, int* tracker, const float* found_inf, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (*found_inf != 0.f) {
+    *scale = *scale * backoff;
+    *tracker = 0;
+  } else {
+    const int succ = *tracker + 1;
+    if (succ == interval) {
+      const float ns = *scale * growth;
+      if (isfinite(ns)) *scale = ns;
+      *tracker = 0;
+    } else {
+      *tracker = succ;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int pp_grad_unscale_check(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off, int n_chunks,
+                                     int chunk, const float* inv_scale, float* found_inf, pp_stream_t s) {
+  PP_CHECK_ARG(tl && tl->n_tensors > 0 && n_chunks > 0 && chunk > 0 && inv_scale && found_inf, "pp_grad_unscale_check: bad arguments");
+  hipLaunchKernelGGL(unscale_check_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)s, *tl, chunk_tensor, chunk_off, chunk,
+                     inv_scale, found_inf);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_amp_update_scale(float* scale, int* growth_tracker, const float* found_inf, float growth_factor,
+                                   float backoff_factor, int growth_interval, pp_stream_t s) {
+  PP_CHECK_ARG(scale && growth_tracker && found_inf && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f &&
+               growth_interval > 0, "pp_amp_update_scale: bad arguments");
+  hipLaunchKernelGGL(amp_update_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, scale, growth_tracker, found_inf,
+                     growth_factor, backoff_factor, growth_interval);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
 
 extern "C" int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off, int n_chunks,
                                 int chunk, float* norms, float lr_scheduled, float b1, float b2, float eps, float weight_decay,

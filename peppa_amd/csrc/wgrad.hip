@@ -31,17 +31,16 @@ struct WGeom {
   FastDiv dRw, dRh, dRt;
 };
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int stride, int col0, int lane) {
+__device__ __forceinline__ h16x8 tr_frag(const unsigned char* tile, int stride, int col0, int lane) {
   // lanes 16g..16g+15 fetch rows {4g..4g+3} and {16+4g..16+4g+3} of columns col0..col0+15;
   // lane (4q+p) supplies the address of row q, columns 4p..4p+3 and receives column (lane&15).
   const int gq = lane >> 4, li = lane & 15;
   const int q = li >> 2, pp = li & 3;
   const unsigned char* a0 = tile + (4 * gq + q) * stride + (col0 + 4 * pp) * 2;
   const unsigned char* a1 = a0 + 16 * stride;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
+  const h16x4 lo = ds_read_tr16(a0);
+  const h16x4 hi = ds_read_tr16(a1);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -57,9 +56,9 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
   constexpr int NQI = 4;                                // Q chunks per thread and step
   constexpr int NPI = (WI * 128 + 255) / 256;           // P chunks per thread and step
   // one LDS object: two loop buffers, the tap table and the four-deep row table (see decode_rows)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + 512 + 4 * MS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + 1024 + 4 * MS * 8];
   int* const lut = (int*)(smem + 2 * BUF);
-  int2* const rowtab = (int2*)(smem + 2 * BUF + 512);
+  int2* const rowtab = (int2*)(smem + 2 * BUF + 1024);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware order (see igemm.hip): the (i, j) tiles of one M-split read the same dY / X rows, so keep
@@ -74,22 +73,22 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
   const int jb = bid % nblk_j; bid /= nblk_j;
   const int split = bid;
   const int z = blockIdx.z;
-  const bfraw* X = (const bfraw*)p.X + z * p.x_s;
-  const bfraw* dY = (const bfraw*)p.dY + z * p.dy_s;
+  const h16raw* X = (const h16raw*)p.X + z * p.x_s;
+  const h16raw* dY = (const h16raw*)p.dY + z * p.dy_s;
   float* __restrict__ dW = p.dW + z * p.dw_s;
   const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)OOB, 0x00020000);
   const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, (short)0, (int)OOB, 0x00020000);
   const pp_gather& g = p.g;
   const int ntaps = g.kt * g.kh * g.kw;
   if (MODE != PP_DENSE) {
-    if (tid < 128) {
+    for (int tp = tid; tp < 256; tp += blockDim.x) {   // up to 256 taps (r3d_18's (3,7,7) stem has 147)
       int e = 0;
-      if (tid < ntaps) {
-        const int dw = tid % g.kw;
-        const int t2 = tid / g.kw;
+      if (tp < ntaps) {
+        const int dw = tp % g.kw;
+        const int t2 = tp / g.kw;
         e = (t2 / g.kh) | ((t2 % g.kh) << 8) | (dw << 16);
       }
-      lut[tid] = e;
+      lut[tp] = e;
     }
     __syncthreads();
   }
@@ -215,13 +214,13 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
     for (int sub = 0; sub < 2; ++sub) {
       const unsigned char* Pt = buf + sub * 32 * PS;
       const unsigned char* Qt = buf + P_BYTES + sub * 32 * QS;
-      const bf16x8 b0 = tr_frag(Qt, QS, (2 * wave) * 16, lane);
-      const bf16x8 b1 = tr_frag(Qt, QS, (2 * wave + 1) * 16, lane);
+      const h16x8 b0 = tr_frag(Qt, QS, (2 * wave) * 16, lane);
+      const h16x8 b1 = tr_frag(Qt, QS, (2 * wave + 1) * 16, lane);
 #pragma unroll
       for (int a = 0; a < WI; ++a) {
-        const bf16x8 af = tr_frag(Pt, PS, a * 16, lane);
-        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b0, acc[a][0], 0, 0, 0);
-        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b1, acc[a][1], 0, 0, 0);
+        const h16x8 af = tr_frag(Pt, PS, a * 16, lane);
+        acc[a][0] = PP_MFMA16(af, b0, acc[a][0], 0, 0, 0);
+        acc[a][1] = PP_MFMA16(af, b1, acc[a][1], 0, 0, 0);
         // keep the scheduler from hoisting every fragment read to the top (register pressure)
         if ((a & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
@@ -353,8 +352,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad_ring_kernel(const pp_wgrad_
   constexpr int NPIECE_P = P_BYTES / 1024, NPIECE_Q = Q_BYTES / 1024;
   static_assert(P_BYTES % 1024 == 0 && Q_BYTES % 1024 == 0, "slabs are whole DMA pieces");
   constexpr int NPP = (NPIECE_P + NWV - 1) / NWV, NPQ = (NPIECE_Q + NWV - 1) / NWV;   // pieces per wave and step
-  static_assert(3 * SLOT + 512 <= 160 * 1024, "ring does not fit the LDS");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SLOT + 512];   // one LDS object (see igemm.hip)
+  static_assert(3 * SLOT + 1024 <= 160 * 1024, "ring does not fit the LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SLOT + 1024];   // one LDS object (see igemm.hip)
   int* const lut = (int*)(smem + 3 * SLOT);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -367,22 +366,22 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad_ring_kernel(const pp_wgrad_
   const int ib = bid % nblk_i; bid /= nblk_i;
   const int jb = bid % nblk_j; bid /= nblk_j;
   const int split = bid;
-  const bfraw* X = (const bfraw*)p.X;
-  const bfraw* dY = (const bfraw*)p.dY;
+  const h16raw* X = (const h16raw*)p.X;
+  const h16raw* dY = (const h16raw*)p.dY;
   float* __restrict__ dW = p.dW;
   const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)OOB, 0x00020000);
   const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, (short)0, (int)OOB, 0x00020000);
   const pp_gather& g = p.g;
   const int ntaps = g.kt * g.kh * g.kw;
   if (MODE != PP_DENSE) {
-    if (tid < 128) {
+    for (int tp = tid; tp < 256; tp += blockDim.x) {   // up to 256 taps (r3d_18's (3,7,7) stem has 147)
       int e = 0;
-      if (tid < ntaps) {
-        const int dw = tid % g.kw;
-        const int t2 = tid / g.kw;
+      if (tp < ntaps) {
+        const int dw = tp % g.kw;
+        const int t2 = tp / g.kw;
         e = (t2 / g.kh) | ((t2 % g.kh) << 8) | (dw << 16);
       }
-      lut[tid] = e;
+      lut[tp] = e;
     }
     __syncthreads();
   }
@@ -473,9 +472,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad_ring_kernel(const pp_wgrad_
   f32x4 bacc[BIAS ? WI : 1];
 #pragma unroll
   for (int a = 0; a < (BIAS ? WI : 1); ++a) bacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 ones;
+  h16x8 ones;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.0f;
+  for (int q = 0; q < 8; ++q) ones[q] = (h16)1.0f;
 
   // Fragment reads go through inline asm: hipcc drains vmcnt (every LDS-DMA in flight) before a
   // ds_read_b64_tr_b16 issued through the builtin, which would serialise the ring.  The asm reads are invisible to
@@ -523,15 +522,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad_ring_kernel(const pp_wgrad_
     }
   };
   auto mfma_frags = [&](const Frags& f) __attribute__((always_inline)) {
-    bf16x8 qf[2];
+    h16x8 qf[2];
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) qf[jj] = __builtin_bit_cast(bf16x8, (u32x4){f.ql[jj][0], f.ql[jj][1], f.qh[jj][0], f.qh[jj][1]});
+    for (int jj = 0; jj < 2; ++jj) qf[jj] = __builtin_bit_cast(h16x8, (u32x4){f.ql[jj][0], f.ql[jj][1], f.qh[jj][0], f.qh[jj][1]});
 #pragma unroll
     for (int a = 0; a < WI; ++a) {
-      const bf16x8 pf = __builtin_bit_cast(bf16x8, (u32x4){f.pl[a][0], f.pl[a][1], f.ph[a][0], f.ph[a][1]});
-      acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[0], acc[a][0], 0, 0, 0);
-      acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[1], acc[a][1], 0, 0, 0);
-      if (BIAS && do_bias) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, ones, bacc[a], 0, 0, 0);
+      const h16x8 pf = __builtin_bit_cast(h16x8, (u32x4){f.pl[a][0], f.pl[a][1], f.ph[a][0], f.ph[a][1]});
+      acc[a][0] = PP_MFMA16(pf, qf[0], acc[a][0], 0, 0, 0);
+      acc[a][1] = PP_MFMA16(pf, qf[1], acc[a][1], 0, 0, 0);
+      if (BIAS && do_bias) bacc[a] = PP_MFMA16(pf, ones, bacc[a], 0, 0, 0);
     }
   };
   auto compute = [&](const unsigned slot_off) __attribute__((always_inline)) {
@@ -694,6 +693,8 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
   PP_CHECK_ARG(d.ldy % 8 == 0 && d.ldy >= ((d.Ni + 7) & ~7), "pp_wgrad: ldy=%d too small/unaligned for Ni=%d", d.ldy, d.Ni);
   PP_CHECK_ARG(d.Kj % 8 == 0 && d.ldw >= d.Kj, "pp_wgrad: Kj=%d must be a multiple of 8 and <= ldw", d.Kj);
   PP_CHECK_ARG(d.g.mode == PP_DENSE || d.g.mode == PP_CONV_FWD, "pp_wgrad: gather mode must be dense or conv-fwd");
+  PP_CHECK_ARG(d.g.mode == PP_DENSE || (d.g.kt > 0 && d.g.kh > 0 && d.g.kw > 0 && d.g.kt * d.g.kh * d.g.kw <= 256 && d.g.kt < 256 &&
+                                        d.g.kh < 256 && d.g.kw < 256), "pp_wgrad: taps %dx%dx%d unsupported (<=256 total)", d.g.kt, d.g.kh, d.g.kw);
   PP_CHECK_ARG(!d.dbias || d.g.mode == PP_DENSE, "pp_wgrad: the fused bias gradient is only built for dense operands");
   PP_CHECK_ARG(((uintptr_t)d.X & 15) == 0 && ((uintptr_t)d.dY & 15) == 0, "pp_wgrad: operands must be 16-byte aligned");
   if (d.nbatch <= 0) d.nbatch = 1;

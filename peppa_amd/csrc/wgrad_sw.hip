@@ -75,7 +75,7 @@ struct SwGeom {
 };
 
 template <int WI>
-__global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const bfraw* __restrict__ X, const bfraw* __restrict__ dY,
+__global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const h16raw* __restrict__ X, const h16raw* __restrict__ dY,
                                                           float* __restrict__ dW, const SwGeom g, const int Ni,
                                                           const int ldy, const int ldw, const int nblk_i,
                                                           const int nblk_c, const int rows_per_split,
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const bfraw* __restrict
     for (int sub = 0; sub < 2; ++sub) {
       // the three X fragments, one after the other (registers are tight at three waves per SIMD): fragment jt + 1
       // is in flight while fragment jt is masked
-      bf16x8 qv[3];
+      h16x8 qv[3];
       QFrag qf[2];
       read_q(mrow0, mpar, sub, 0, qf[0]);
 #pragma unroll
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const bfraw* __restrict
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.lo), "+v"(f.hi), "+v"(f.mlo), "+v"(f.mhi) : : "memory");
         }
-        qv[jt] = __builtin_bit_cast(bf16x8, (u32x4){f.lo[0] & f.mlo[0], f.lo[1] & f.mlo[1], f.hi[0] & f.mhi[0], f.hi[1] & f.mhi[1]});
+        qv[jt] = __builtin_bit_cast(h16x8, (u32x4){f.lo[0] & f.mlo[0], f.lo[1] & f.mlo[1], f.hi[0] & f.mhi[0], f.hi[1] & f.mhi[1]});
       }
       const unsigned pa = p_lane + pslot + (unsigned)(sub * 32 * PS);
       u32x2 plo[2], phi[2];
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const bfraw* __restrict
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo[cur]), "+v"(phi[cur]) : : "memory");
         }
-        const bf16x8 pv = __builtin_bit_cast(bf16x8, (u32x4){plo[cur][0], plo[cur][1], phi[cur][0], phi[cur][1]});
+        const h16x8 pv = __builtin_bit_cast(h16x8, (u32x4){plo[cur][0], plo[cur][1], phi[cur][0], phi[cur][1]});
 #pragma unroll
-        for (int jt = 0; jt < 3; ++jt) acc[a][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pv, qv[jt], acc[a][jt], 0, 0, 0);
+        for (int jt = 0; jt < 3; ++jt) acc[a][jt] = PP_MFMA16(pv, qv[jt], acc[a][jt], 0, 0, 0);
       });
     }
   };
@@ -339,7 +339,7 @@ int launch_sw(const pp_wgrad_desc& d, hipStream_t s) {
   msplit = (int)((steps + sps - 1) / sps);
   const int rows_per_split = (int)(sps * MS);
   dim3 grid((unsigned)(tiles * msplit), 1, 1), block(NT);
-  hipLaunchKernelGGL((wgrad_sw_kernel<WI>), grid, block, 0, s, (const bfraw*)d.X, (const bfraw*)d.dY, d.dW, g, d.Ni, d.ldy,
+  hipLaunchKernelGGL((wgrad_sw_kernel<WI>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
                      d.ldw, nblk_i, nblk_c, rows_per_split, pp_opt_xcd_remap_wgrad);
   PP_LAUNCH_CHECK();
   return PP_OK;

@@ -70,7 +70,7 @@ struct TwGeom {
 };
 
 template <int WI>
-__global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const bfraw* __restrict__ X, const bfraw* __restrict__ dY,
+__global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const h16raw* __restrict__ X, const h16raw* __restrict__ dY,
                                                           float* __restrict__ dW, const TwGeom g, const int Ni,
                                                           const int ldy, const int ldw, const int nblk_i,
                                                           const int nblk_c, const int steps_per_split,
@@ -200,9 +200,9 @@ __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const bfraw* __restrict
                    : "+v"(qlo[0]), "+v"(qhi[0]), "+v"(qlo[1]), "+v"(qhi[1]), "+v"(qlo[2]), "+v"(qhi[2])
                    :
                    : "memory");
-      bf16x8 qv[3];
+      h16x8 qv[3];
 #pragma unroll
-      for (int jt = 0; jt < 3; ++jt) qv[jt] = __builtin_bit_cast(bf16x8, (u32x4){qlo[jt][0], qlo[jt][1], qhi[jt][0], qhi[jt][1]});
+      for (int jt = 0; jt < 3; ++jt) qv[jt] = __builtin_bit_cast(h16x8, (u32x4){qlo[jt][0], qlo[jt][1], qhi[jt][0], qhi[jt][1]});
       static_for<0, WI>([&](auto ic) __attribute__((always_inline)) {
         constexpr int a = decltype(ic)::value;
         constexpr int cur = a & 1;
@@ -213,9 +213,9 @@ __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const bfraw* __restrict
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(plo[cur]), "+v"(phi[cur]) : : "memory");
         }
-        const bf16x8 pv = __builtin_bit_cast(bf16x8, (u32x4){plo[cur][0], plo[cur][1], phi[cur][0], phi[cur][1]});
+        const h16x8 pv = __builtin_bit_cast(h16x8, (u32x4){plo[cur][0], plo[cur][1], phi[cur][0], phi[cur][1]});
 #pragma unroll
-        for (int jt = 0; jt < 3; ++jt) acc[a][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pv, qv[jt], acc[a][jt], 0, 0, 0);
+        for (int jt = 0; jt < 3; ++jt) acc[a][jt] = PP_MFMA16(pv, qv[jt], acc[a][jt], 0, 0, 0);
       });
     }
   };
@@ -288,7 +288,7 @@ int launch_tw(const pp_wgrad_desc& d, hipStream_t s) {
   const int sps = (g.NS + msplit - 1) / msplit;
   msplit = (g.NS + sps - 1) / sps;
   dim3 grid((unsigned)(tiles * msplit), 1, 1), block(NT);
-  hipLaunchKernelGGL((wgrad_tw_kernel<WI>), grid, block, 0, s, (const bfraw*)d.X, (const bfraw*)d.dY, d.dW, g, d.Ni, d.ldy,
+  hipLaunchKernelGGL((wgrad_tw_kernel<WI>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
                      d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad);
   PP_LAUNCH_CHECK();
   return PP_OK;

@@ -7,11 +7,33 @@ computes with torch ops, and there is no fallback when a tensor is not on the GP
 import ctypes as C
 import torch
 
+from . import _lib
 from ._lib import call, Gather, IGemmDesc, WGradDesc, TensorList, PeppaHipError
 
 DENSE, CONV_FWD, CONV_DGRAD = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-bf16, f32 = torch.bfloat16, torch.float32
+f32 = torch.float32
+_DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def act16():
+    """torch dtype of the 16-bit operands / activations of the library `call` currently dispatches to."""
+    return _DTYPES[_lib.PRECISION]
+
+
+def precision():
+    return _lib.PRECISION
+
+
+def set_precision(p):
+    """"bf16" (libpeppa_hip.so, the default: BASELINE configs[1]) or "fp16" (libpeppa_hip_f16.so: the reference's
+    `precision: 16`, BASELINE configs[4]); returns the previous setting."""
+    p = {"16": "fp16", 16: "fp16", "half": "fp16", "float16": "fp16", "bfloat16": "bf16"}.get(p, p)
+    if p not in _DTYPES:
+        raise ValueError(f"precision must be 'bf16' or 'fp16', got {p!r}")
+    prev, _lib.PRECISION = _lib.PRECISION, p
+    return prev
+
 
 
 def _s():
@@ -123,11 +145,11 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
     if dropout is not None and dropout[0] > 0:     # (p, seed): the mask of dropout_bf16 on the flat output
         d.drop_p, d.drop_seed = float(dropout[0]), int(dropout[1]) & 0xffffffff
     d.M, d.N, d.K, d.g = M, N, K, g
-    d.A, d.Bt, d.ldb, d.b_rows = _p(A, bf16), _p(Bt, bf16), ldb, b_rows
+    d.A, d.Bt, d.ldb, d.b_rows = _p(A, act16()), _p(Bt, act16()), ldb, b_rows
     d.C, d.ldc, d.c_fp32 = _p(Cout), ldc, int(Cout.dtype == f32)
-    d.Cpre = _p(Cpre, bf16)
+    d.Cpre = _p(Cpre, act16())
     d.bias, d.act = _p(bias, f32), act
-    d.residual, d.ldr = _p(residual, bf16), ldr
+    d.residual, d.ldr = _p(residual, act16()), ldr
     d.colstats, d.ldstat = _p(colstats, f32), ldstat
     d.nbatch, d.inner = nbatch, inner
     d.a_s0, d.a_s1 = a_s
@@ -144,7 +166,7 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
 def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0, dbias=None, dbias_s=0):
     d = WGradDesc()
     d.M, d.Ni, d.Kj, d.g = M, Ni, Kj, g
-    d.X, d.dY, d.ldy, d.dW, d.ldw = _p(X, bf16), _p(dY, bf16), ldy, _p(dW, f32), ldw
+    d.X, d.dY, d.ldy, d.dW, d.ldw = _p(X, act16()), _p(dY, act16()), ldy, _p(dW, f32), ldw
     d.msplit, d.nbatch, d.x_s, d.dy_s, d.dw_s = msplit, nbatch, x_s, dy_s, dw_s
     d.dbias, d.dbias_s = _p(dbias, f32), dbias_s
     _profiled(f"{_wgrad_family(g)}<{_MODE_NAMES[g.mode]}> Ni={Ni} Kj={Kj}", 2.0 * M * Ni * Kj * nbatch,
@@ -153,13 +175,13 @@ def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=
 
 # ---- weight preparation ----------------------------------------------------------------------
 def prep_conv_weight(w, out, Co, Ci, taps, rows_out, cg, transpose_io=False, flip=False, scale=1.0):
-    call("pp_prep_conv_weight", _p(w, f32), Co, Ci, taps, _p(out, bf16), rows_out, cg, int(transpose_io), int(flip),
+    call("pp_prep_conv_weight", _p(w, f32), Co, Ci, taps, _p(out, act16()), rows_out, cg, int(transpose_io), int(flip),
          scale, _s())
 
 
 def select_taps(w, out, rows, taps, cg, sel):
     arr = (C.c_int * len(sel))(*sel)
-    call("pp_select_taps", _p(w, bf16), rows, taps, cg, arr, len(sel), _p(out, bf16), _s())
+    call("pp_select_taps", _p(w, act16()), rows, taps, cg, arr, len(sel), _p(out, act16()), _s())
 
 
 def unprep_conv_grad(g, dw, Co, Ci, taps, cg):
@@ -167,16 +189,16 @@ def unprep_conv_grad(g, dw, Co, Ci, taps, cg):
 
 
 def cast_pad_2d(inp, out, rows, cols, ld_in, rows_out, ld_out, transpose=False, cols_out=None):
-    call("pp_cast_pad_2d", _p(inp, f32), rows, cols, ld_in, _p(out, bf16), rows_out,
+    call("pp_cast_pad_2d", _p(inp, f32), rows, cols, ld_in, _p(out, act16()), rows_out,
          ld_out if cols_out is None else cols_out, ld_out, int(transpose), _s())
 
 
 def cast_f32_to_bf16(inp, out):
-    call("pp_cast_f32_to_bf16", _p(inp, f32), _p(out, bf16), inp.numel(), _s())
+    call("pp_cast_f32_to_bf16", _p(inp, f32), _p(out, act16()), inp.numel(), _s())
 
 
 def cast_bf16_to_f32(inp, out):
-    call("pp_cast_bf16_to_f32", _p(inp, bf16), _p(out, f32), inp.numel(), _s())
+    call("pp_cast_bf16_to_f32", _p(inp, act16()), _p(out, f32), inp.numel(), _s())
 
 
 def cast_pad_2d_multi(jobs, device):
@@ -196,7 +218,7 @@ def copy_2d_f32(inp, ld_in, out, ld_out, rows, cols):
 
 
 def transpose_bf16(inp, in_bs, ld_in, out, out_bs, ld_out, nb, R, Ccols, inner=1, in_s1=0, out_s1=0, r_pad=0):
-    call("pp_transpose_bf16", _p(inp, bf16), in_bs, ld_in, _p(out, bf16), out_bs, ld_out, nb, R, Ccols, inner,
+    call("pp_transpose_bf16", _p(inp, act16()), in_bs, ld_in, _p(out, act16()), out_bs, ld_out, nb, R, Ccols, inner,
          in_s1, out_s1, r_pad, _s())
 
 
@@ -208,17 +230,17 @@ def video_normalize_ndhwc(x, out, mean3, std3):
     B, _, T, H, W = x.shape
     m = (C.c_float * 3)(*mean3)
     sd = (C.c_float * 3)(*std3)
-    call("pp_video_normalize_ndhwc", _p(x, f32), _p(out, bf16), B, T, H, W, m, sd, _s())
+    call("pp_video_normalize_ndhwc", _p(x, f32), _p(out, act16()), B, T, H, W, m, sd, _s())
 
 
 def video_normalize_u8_ndhwc(x, out, mean3, std3):
-    """x uint8 (B,T,H,W,3) contiguous -> out bf16 [B*T*H*W][8]."""
+    """x uint8 (B,T,H,W,3) contiguous -> out 16-bit [B*T*H*W][8]."""
     B, T, H, W, c = x.shape
     if c != 3 or x.dtype != torch.uint8 or not x.is_contiguous():
         raise PeppaHipError(f"uint8 video must be contiguous (B,T,H,W,3), got {tuple(x.shape)} {x.dtype}")
     m = (C.c_float * 3)(*mean3)
     sd = (C.c_float * 3)(*std3)
-    call("pp_video_normalize_u8_ndhwc", x.data_ptr(), _p(out, bf16), B, T, H, W, m, sd, _s())
+    call("pp_video_normalize_u8_ndhwc", x.data_ptr(), _p(out, act16()), B, T, H, W, m, sd, _s())
 
 
 def collate_video_u8(table, n, Tmax, H, W, out):
@@ -234,11 +256,11 @@ def collate_rows(table, n, row_bytes, out):
 
 
 def maxpool3x3s2_fwd(x, y, N, Hh, W, Cp):
-    call("pp_maxpool3x3s2_fwd", _p(x, bf16), _p(y, bf16), N, Hh, W, Cp, _s())
+    call("pp_maxpool3x3s2_fwd", _p(x, act16()), _p(y, act16()), N, Hh, W, Cp, _s())
 
 
 def maxpool3x3s2_bwd(x, dy, dx, N, Hh, W, Cp):
-    call("pp_maxpool3x3s2_bwd", _p(x, bf16), _p(dy, bf16), _p(dx, bf16), N, Hh, W, Cp, _s())
+    call("pp_maxpool3x3s2_bwd", _p(x, act16()), _p(dy, act16()), _p(dx, act16()), N, Hh, W, Cp, _s())
 
 
 # ---- batch norm -----------------------------------------------------------------------------------
@@ -259,15 +281,15 @@ def bn_eval_affine(gamma, beta, rmean, rvar, eps, Cn, Cp, scale, shift):
 
 
 def colstats_bf16(y, M, Cp, partials, nblk):
-    call("pp_colstats_bf16", _p(y, bf16), M, Cp, _p(partials, f32), nblk, _s())
+    call("pp_colstats_bf16", _p(y, act16()), M, Cp, _p(partials, f32), nblk, _s())
 
 
 def bn_apply(y, scale, shift, res, relu, z, M, Cp):
-    call("pp_bn_apply", _p(y, bf16), _p(scale, f32), _p(shift, f32), _p(res, bf16), int(relu), _p(z, bf16), M, Cp, _s())
+    call("pp_bn_apply", _p(y, act16()), _p(scale, f32), _p(shift, f32), _p(res, act16()), int(relu), _p(z, act16()), M, Cp, _s())
 
 
 def bn_bwd_reduce(dz, y, z, mean, rstd, scale, shift, relu, partials, nblk, M, Cp):
-    call("pp_bn_bwd_reduce", _p(dz, bf16), _p(y, bf16), _p(z, bf16), _p(mean, f32), _p(rstd, f32), _p(scale, f32),
+    call("pp_bn_bwd_reduce", _p(dz, act16()), _p(y, act16()), _p(z, act16()), _p(mean, f32), _p(rstd, f32), _p(scale, f32),
          _p(shift, f32), int(relu), _p(partials, f32), nblk, M, Cp, _s())
 
 
@@ -277,29 +299,29 @@ def bn_bwd_finalize(partials, nblk, count, Cn, Cp, gamma, rstd, dgamma, dbeta, c
 
 
 def bn_bwd_apply(dz, y, z, mean, rstd, coef, scale, shift, relu, dy, dres, M, Cp):
-    call("pp_bn_bwd_apply", _p(dz, bf16), _p(y, bf16), _p(z, bf16), _p(mean, f32), _p(rstd, f32), _p(coef, f32),
-         _p(scale, f32), _p(shift, f32), int(relu), _p(dy, bf16), _p(dres, bf16), M, Cp, _s())
+    call("pp_bn_bwd_apply", _p(dz, act16()), _p(y, act16()), _p(z, act16()), _p(mean, f32), _p(rstd, f32), _p(coef, f32),
+         _p(scale, f32), _p(shift, f32), int(relu), _p(dy, act16()), _p(dres, act16()), M, Cp, _s())
 
 
 # ---- elementwise ----------------------------------------------------------------------------------
 def gelu_fwd(x, y):
-    call("pp_gelu_fwd", _p(x, bf16), _p(y, bf16), x.numel(), _s())
+    call("pp_gelu_fwd", _p(x, act16()), _p(y, act16()), x.numel(), _s())
 
 
 def gelu_bwd(dy, x, dx):
-    call("pp_gelu_bwd", _p(dy, bf16), _p(x, bf16), _p(dx, bf16), x.numel(), _s())
+    call("pp_gelu_bwd", _p(dy, act16()), _p(x, act16()), _p(dx, act16()), x.numel(), _s())
 
 
 def gelu_bwd_dropout(dy, x, dx, p, seed):
-    call("pp_gelu_bwd_dropout", _p(dy, bf16), _p(x, bf16), _p(dx, bf16), x.numel(), float(p), int(seed) & 0xffffffff, _s())
+    call("pp_gelu_bwd_dropout", _p(dy, act16()), _p(x, act16()), _p(dx, act16()), x.numel(), float(p), int(seed) & 0xffffffff, _s())
 
 
 def add_bf16(a, b, out):
-    call("pp_add_bf16", _p(a, bf16), _p(b, bf16), _p(out, bf16), a.numel(), _s())
+    call("pp_add_bf16", _p(a, act16()), _p(b, act16()), _p(out, act16()), a.numel(), _s())
 
 
 def dropout_bf16(x, y, p, seed, res=None):
-    call("pp_dropout_bf16", _p(x, bf16), _p(res, bf16), _p(y, bf16), x.numel(), float(p), int(seed) & 0xffffffff, _s())
+    call("pp_dropout_bf16", _p(x, act16()), _p(res, act16()), _p(y, act16()), x.numel(), float(p), int(seed) & 0xffffffff, _s())
 
 
 def dropout_f32(x, y, p, seed):
@@ -307,36 +329,36 @@ def dropout_f32(x, y, p, seed):
 
 
 def colsum_bf16(x, M, N, ld, out):
-    call("pp_colsum_bf16", _p(x, bf16), M, N, ld, _p(out, f32), _s())
+    call("pp_colsum_bf16", _p(x, act16()), M, N, ld, _p(out, f32), _s())
 
 
 # ---- layer norm / softmax -------------------------------------------------------------------------
 def layernorm_fwd(x, gamma, beta, eps, y, mean, rstd, rows, D):
-    call("pp_layernorm_fwd", _p(x, bf16), _p(gamma, f32), _p(beta, f32), eps, _p(y, bf16), _p(mean, f32),
+    call("pp_layernorm_fwd", _p(x, act16()), _p(gamma, f32), _p(beta, f32), eps, _p(y, act16()), _p(mean, f32),
          _p(rstd, f32), rows, D, _s())
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, ws=None):
     """ws: optional fp32 scratch [blocks][2][D] -> two-pass (deterministic) dgamma / dbeta instead of atomics."""
-    call("pp_layernorm_bwd", _p(dy, bf16), _p(x, bf16), _p(gamma, f32), _p(mean, f32), _p(rstd, f32), _p(dx, bf16),
+    call("pp_layernorm_bwd", _p(dy, act16()), _p(x, act16()), _p(gamma, f32), _p(mean, f32), _p(rstd, f32), _p(dx, act16()),
          _p(dgamma, f32), _p(dbeta, f32), rows, D, _p(ws, f32), 0 if ws is None else ws.shape[0], _s())
 
 
 def attention_fwd(qkv, B, T, heads, scale, p, seed, ctx):
-    call("pp_attention_fwd", _p(qkv, bf16), B, T, heads, float(scale), float(p), int(seed) & 0xffffffff, _p(ctx, bf16), _s())
+    call("pp_attention_fwd", _p(qkv, act16()), B, T, heads, float(scale), float(p), int(seed) & 0xffffffff, _p(ctx, act16()), _s())
 
 
 def attention_bwd(qkv, dctx, B, T, heads, scale, p, seed, dqkv):
-    call("pp_attention_bwd", _p(qkv, bf16), _p(dctx, bf16), B, T, heads, float(scale), float(p), int(seed) & 0xffffffff,
-         _p(dqkv, bf16), _s())
+    call("pp_attention_bwd", _p(qkv, act16()), _p(dctx, act16()), B, T, heads, float(scale), float(p), int(seed) & 0xffffffff,
+         _p(dqkv, act16()), _s())
 
 
 def softmax_fwd(S, lds, P, ldp, nb, T, scale):
-    call("pp_softmax_fwd", _p(S, f32), lds, _p(P, bf16), ldp, nb, T, scale, _s())
+    call("pp_softmax_fwd", _p(S, f32), lds, _p(P, act16()), ldp, nb, T, scale, _s())
 
 
 def softmax_bwd(dP, lds, P, ldp, dS, nb, T, scale):
-    call("pp_softmax_bwd", _p(dP, f32), lds, _p(P, bf16), ldp, _p(dS, bf16), nb, T, scale, _s())
+    call("pp_softmax_bwd", _p(dP, f32), lds, _p(P, act16()), ldp, _p(dS, act16()), nb, T, scale, _s())
 
 
 # ---- wav2vec2 conv0 + groupnorm, weight norm --------------------------------------------------------
@@ -346,21 +368,21 @@ def conv0_stats(wave, B, L, T0, w, stats):
 
 def conv0_apply(wave, B, L, T0, w, stats, gamma, beta, eps, out):
     call("pp_conv0_apply", _p(wave, f32), B, L, T0, _p(w, f32), _p(stats, f32), _p(gamma, f32), _p(beta, f32), eps,
-         _p(out, bf16), _s())
+         _p(out, act16()), _s())
 
 
 def conv0_bwd_reduce(wave, B, L, T0, w, stats, gamma, beta, eps, dout, red):
     call("pp_conv0_bwd_reduce", _p(wave, f32), B, L, T0, _p(w, f32), _p(stats, f32), _p(gamma, f32), _p(beta, f32),
-         eps, _p(dout, bf16), _p(red, f32), _s())
+         eps, _p(dout, act16()), _p(red, f32), _s())
 
 
 def conv0_bwd_apply(wave, B, L, T0, w, stats, gamma, beta, eps, dout, red, dw, dgamma, dbeta):
     call("pp_conv0_bwd_apply", _p(wave, f32), B, L, T0, _p(w, f32), _p(stats, f32), _p(gamma, f32), _p(beta, f32),
-         eps, _p(dout, bf16), _p(red, f32), _p(dw, f32), _p(dgamma, f32), _p(dbeta, f32), _s())
+         eps, _p(dout, act16()), _p(red, f32), _p(dw, f32), _p(dgamma, f32), _p(dbeta, f32), _s())
 
 
 def weightnorm_fwd(v, g, Co, Ci, Kk, norm, out):
-    call("pp_weightnorm_fwd", _p(v, f32), _p(g, f32), Co, Ci, Kk, _p(norm, f32), _p(out, bf16), _s())
+    call("pp_weightnorm_fwd", _p(v, f32), _p(g, f32), Co, Ci, Kk, _p(norm, f32), _p(out, act16()), _s())
 
 
 def weightnorm_bwd(dwt, v, g, norm, Co, Ci, Kk, dv, dg, dot_ws):
@@ -370,11 +392,11 @@ def weightnorm_bwd(dwt, v, g, norm, Co, Ci, Kk, dv, dg, dot_ws):
 
 # ---- heads ------------------------------------------------------------------------------------------
 def spatial_mean_fwd(x, out, B, T, HW, Cn, Cp):
-    call("pp_spatial_mean_fwd", _p(x, bf16), _p(out, f32), B, T, HW, Cn, Cp, _s())
+    call("pp_spatial_mean_fwd", _p(x, act16()), _p(out, f32), B, T, HW, Cn, Cp, _s())
 
 
 def spatial_mean_bwd(dout, dx, B, T, HW, Cn, Cp):
-    call("pp_spatial_mean_bwd", _p(dout, f32), _p(dx, bf16), B, T, HW, Cn, Cp, _s())
+    call("pp_spatial_mean_bwd", _p(dout, f32), _p(dx, act16()), B, T, HW, Cn, Cp, _s())
 
 
 def avgpool_tf_fwd(x, out, B, T, F, S):

@@ -1,6 +1,6 @@
 """Forward/backward primitives of the hot path, expressed over the C ABI (peppa_amd.hip).
 
-Each primitive is an explicit (forward, backward) pair on channels-last bf16 activations;
+Each primitive is an explicit (forward, backward) pair on channels-last 16-bit activations;
 the encoders (video.py / audio.py) chain them inside one autograd.Function per encoder, so
 activation buffers, weight operand layouts and streams are managed by hand instead of by a
 tracing compiler.  No torch arithmetic happens here: torch only allocates.
@@ -8,7 +8,7 @@ tracing compiler.  No torch arithmetic happens here: torch only allocates.
 import torch
 
 from . import hip as H
-from .hip import rup, bf16, f32
+from .hip import rup, act16, f32
 
 CP = 16  # channel padding of activation tensors
 
@@ -102,18 +102,18 @@ class ConvGeom:
 
 
 def prep_conv_weights(w, geom, need_dgrad=True):
-    """fp32 master [Co][Ci/groups][taps...] -> bf16 operands (forward, dgrad)."""
+    """fp32 master [Co][Ci/groups][taps...] -> 16-bit operands (forward, dgrad)."""
     Co, Cig, taps = geom.Co, geom.Cig, geom.taps
-    wf = empty((Co, taps, geom.cg_in), bf16, w)
+    wf = empty((Co, taps, geom.cg_in), act16(), w)
     H.prep_conv_weight(w, wf, Co, Cig, taps, Co, geom.cg_in)
     wd = None
     if need_dgrad:
         if geom.groups == 1:
-            wd = empty((geom.Ci, taps, geom.cg_out), bf16, w)
+            wd = empty((geom.Ci, taps, geom.cg_out), act16(), w)
             H.prep_conv_weight(w, wd, Co, geom.Ci, taps, geom.Ci, geom.cg_out, transpose_io=True)
         else:
             # per group g: rows = ci (Cig), reduce = (tap, co in group)
-            wd = empty((geom.groups, Cig, taps, geom.Cog), bf16, w)
+            wd = empty((geom.groups, Cig, taps, geom.Cog), act16(), w)
             for gi in range(geom.groups):
                 H.prep_conv_weight(w[gi * geom.Cog:(gi + 1) * geom.Cog], wd[gi], geom.Cog, Cig, taps, Cig, geom.Cog,
                                    transpose_io=True)
@@ -122,7 +122,7 @@ def prep_conv_weights(w, geom, need_dgrad=True):
 
 def conv_fwd(x, geom, wf, *, stats=False, bias=None, act=H.ACT_NONE, out=None, pre=None):
     """y[M][out_cstride] = conv(x); optional per-column partial sums for BatchNorm."""
-    y = out if out is not None else empty((geom.M, geom.out_cstride), bf16, x)
+    y = out if out is not None else empty((geom.M, geom.out_cstride), act16(), x)
     partials = empty((geom.nblk, 2, geom.out_cstride), f32, x) if stats else None
     if geom.groups == 1:
         H.igemm(x, wf, y, geom.M, geom.out_cstride, geom.Kf, geom.g_fwd(), geom.Kf, geom.out_cstride,
@@ -156,14 +156,14 @@ def _conv_dgrad_strided(dy, geom, wd, residual):
     classes = _parity_classes(geom)
     empty_class = any(len(t) == 0 for cls in classes for (_, t, _, _) in cls)
     assert not (empty_class and residual is not None)
-    dx = (zeros if empty_class else empty)((geom.Min, geom.in_cstride), bf16, dy)
+    dx = (zeros if empty_class else empty)((geom.Min, geom.in_cstride), act16(), dy)
     kt, kh, kw = geom.k
     for cls in classes:
         (qt, tt, ct, Rt), (qh, th, ch, Rh), (qw, tw, cw, Rw) = cls
         if not (tt and th and tw) or Rt * Rh * Rw == 0:
             continue
         sel = [(a * kh + b) * kw + c for a in tt for b in th for c in tw]
-        wsel = empty((geom.Ci, len(sel), geom.cg_out), bf16, dy)
+        wsel = empty((geom.Ci, len(sel), geom.cg_out), act16(), dy)
         H.select_taps(wd, wsel, geom.Ci, geom.taps, geom.cg_out, sel)
         g = H.gather_conv(H.CONV_DGRAD, (Rt, Rh, Rw), (geom.To, geom.Ho, geom.Wo), (len(tt), len(th), len(tw)), (1, 1, 1),
                           (ct, ch, cw), geom.cg_out, geom.out_cstride)
@@ -178,7 +178,7 @@ def conv_dgrad(dy, geom, wd, *, residual=None):
     """dx[Min][in_cstride] = conv^T(dy) (+ residual)."""
     if geom.groups == 1 and max(geom.s) == 2:
         return _conv_dgrad_strided(dy, geom, wd, residual)
-    dx = empty((geom.Min, geom.in_cstride), bf16, dy)
+    dx = empty((geom.Min, geom.in_cstride), act16(), dy)
     if geom.groups == 1:
         H.igemm(dy, wd, dx, geom.Min, geom.in_cstride, geom.Kd, geom.g_dgrad(), geom.Kd, geom.in_cstride,
                 b_rows=geom.Ci, residual=residual, ldr=geom.in_cstride)
@@ -245,7 +245,7 @@ def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momen
         H.bn_finalize(partials, nblk, Cp, count, C, Cp, bn.weight, bn.bias, eps, momentum,
                       bn.running_mean if update_running else None, bn.running_var if update_running else None,
                       sv.mean, sv.rstd, sv.scale, sv.shift, ws)
-    z = empty(y.shape, bf16, y)
+    z = empty(y.shape, act16(), y)
     H.bn_apply(y, sv.scale, sv.shift, residual, relu, z, y.shape[0], Cp)
     return z, sv
 
@@ -265,22 +265,22 @@ def bn_bwd(dz, y, z, sv, gamma, *, relu, want_dres=False):
         # -- the means of g and g * xhat -- are those of the global batch (sv.count already is the global count)
         scratch = empty((2, sv.C), f32, y)
         H.bn_bwd_finalize(_global_sums(partials, nblk, Cp), 1, sv.count, sv.C, Cp, gamma, sv.rstd, scratch[0], scratch[1], coef)
-    dy = empty(y.shape, bf16, y)
-    dres = empty(y.shape, bf16, y) if want_dres else None
+    dy = empty(y.shape, act16(), y)
+    dres = empty(y.shape, act16(), y) if want_dres else None
     H.bn_bwd_apply(dz, y, z, sv.mean, sv.rstd, coef, sv.scale, sv.shift, relu, dy, dres, M, Cp)
     return dy, dres, dgamma, dbeta
 
 
 # ---- Linear (dense GEMM) ------------------------------------------------------------------------------
 def prep_linear(w, need_dgrad=True):
-    """w fp32 [N][K] -> (bf16 [N][Kp], bf16 transposed [K][Np]) with Kp, Np multiples of 16."""
+    """w fp32 [N][K] -> (16-bit [N][Kp], 16-bit transposed [K][Np]) with Kp, Np multiples of 16."""
     N, K = w.shape
     Kp, Np = cpad(K), cpad(N)
-    wf = empty((N, Kp), bf16, w)
+    wf = empty((N, Kp), act16(), w)
     H.cast_pad_2d(w, wf, N, K, K, N, Kp)
     wt = None
     if need_dgrad:
-        wt = empty((K, Np), bf16, w)
+        wt = empty((K, Np), act16(), w)
         H.cast_pad_2d(w, wt, K, N, K, K, Np, transpose=True)
     return wf, wt
 
@@ -296,14 +296,14 @@ class CastBatch:
         self.jobs.append((w, out, rows, cols, ld_in, rows_out, cols_out, ld_out, transpose, out_f32))
 
     def linear(self, w, need_dgrad=True):
-        """Same operands as prep_linear: (bf16 [N][Kp], bf16 transposed [K][Np] or None)."""
+        """Same operands as prep_linear: (16-bit [N][Kp], 16-bit transposed [K][Np] or None)."""
         N, K = w.shape
         Kp, Np = cpad(K), cpad(N)
-        wf = empty((N, Kp), bf16, w)
+        wf = empty((N, Kp), act16(), w)
         self.cast(w, wf, N, K, K, N, Kp, Kp)
         wt = None
         if need_dgrad:
-            wt = empty((K, Np), bf16, w)
+            wt = empty((K, Np), act16(), w)
             self.cast(w, wt, K, N, K, K, Np, Np, transpose=True)
         return wf, wt
 
@@ -314,10 +314,10 @@ class CastBatch:
 
 
 def linear_fwd(x, M, wf, N, *, bias=None, act=H.ACT_NONE, residual=None, pre=None, out=None, out_f32=False, dropout=None):
-    """x bf16 [M][Kp] -> y [M][Np] = dropout(act(x W^T + bias)) + residual; `pre` receives the pre-activation."""
+    """x 16-bit [M][Kp] -> y [M][Np] = dropout(act(x W^T + bias)) + residual; `pre` receives the pre-activation."""
     Kp = wf.shape[1]
     Np = cpad(N)
-    y = out if out is not None else empty((M, Np), f32 if out_f32 else bf16, x)
+    y = out if out is not None else empty((M, Np), f32 if out_f32 else act16(), x)
     H.igemm(x, wf, y, M, N, Kp, H.gather_dense(x.shape[1]), Kp, Np, b_rows=N, bias=bias, act=act, residual=residual,
             ldr=Np, Cpre=pre, dropout=dropout)
     return y
@@ -327,7 +327,7 @@ def linear_dgrad(dy, M, wt, K, *, residual=None):
     """dx [M][Kp] = dy [M][Np] @ W ; wt is the transposed operand [K][Np]."""
     Np = wt.shape[1]
     Kp = cpad(K)
-    dx = empty((M, Kp), bf16, dy)
+    dx = empty((M, Kp), act16(), dy)
     H.igemm(dy, wt, dx, M, K, Np, H.gather_dense(dy.shape[1]), Np, Kp, b_rows=K, residual=residual, ldr=Kp)
     return dx
 
@@ -351,7 +351,7 @@ def linear_wgrad(x, dy, M, N, K, *, want_bias=True):
 # ---- LayerNorm ---------------------------------------------------------------------------------------
 def layernorm_fwd(x, ln, eps=1e-5):
     rows, D = x.shape
-    y = empty(x.shape, bf16, x)
+    y = empty(x.shape, act16(), x)
     mean, rstd = empty((rows,), f32, x), empty((rows,), f32, x)
     H.layernorm_fwd(x, ln.weight, ln.bias, eps, y, mean, rstd, rows, D)
     return y, (mean, rstd)
@@ -359,7 +359,7 @@ def layernorm_fwd(x, ln, eps=1e-5):
 
 def layernorm_bwd(dy, x, ln, saved):
     rows, D = x.shape
-    dx = empty(x.shape, bf16, x)
+    dx = empty(x.shape, act16(), x)
     dg, db = zeros((D,), f32, x), zeros((D,), f32, x)
     ws = empty((min(512, (rows + 15) // 16), 2, D), f32, x)   # per-workgroup partials (4 waves x 4 rows each)
     H.layernorm_bwd(dy, x, ln.weight, saved[0], saved[1], dx, dg, db, rows, D, ws)

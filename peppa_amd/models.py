@@ -10,7 +10,7 @@ from . import hip as H
 from . import layers as L
 from . import audio as A
 from . import video as V
-from .hip import f32, bf16
+from .hip import f32, act16
 from .loss import TripletLoss
 from . import metrics as _metrics
 from . import optimization as opt
@@ -293,7 +293,7 @@ class VideoTrunkFn(torch.autograd.Function):
         B, Tn, HW, Cp = ctx.dims
         grads = grad_dict()
         with torch.no_grad():
-            dz = torch.empty(B * Tn * HW, Cp, dtype=bf16, device=dout.device)
+            dz = torch.empty(B * Tn * HW, Cp, dtype=act16(), device=dout.device)
             H.spatial_mean_bwd(dout.contiguous().float(), dz, B, Tn, HW, 512, Cp)
             with L.ZeroPool("video", dout.device):
                 V.trunk_backward(ctx.tape, dz, grads)

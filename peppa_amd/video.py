@@ -11,7 +11,7 @@ from torch import nn
 
 from . import hip as H
 from . import layers as L
-from .hip import bf16, f32
+from .hip import act16, f32
 
 VIDEO_STATS = {  # data/out/stats.pt, data/out/kinetics-stats.pt, pig/models.py:335-336
     "peppa": ((0.62745821, 0.66273642, 0.66865104), (0.24167268, 0.20884572, 0.27490067)),
@@ -203,21 +203,21 @@ class _Tape:
 
 
 def trunk_forward(net, x, norm_kind, training, save):
-    """x fp32 [B][3][T][H][W] (or uint8 [B][T][H][W][3]) -> (z bf16 [B*T'*H'*W'][512], (T',H',W'), tape)."""
+    """x fp32 [B][3][T][H][W] (or uint8 [B][T][H][W][3]) -> (z 16-bit [B*T'*H'*W'][512], (T',H',W'), tape)."""
     mean, std = VIDEO_STATS[norm_kind]
     if x.dtype == torch.uint8:               # padded decoder frames (B,T,H,W,3) from data.collate_device
         B, T, Hh, W, _ = x.shape
-        cur = L.empty((B * T * Hh * W, 8), bf16, x)
+        cur = L.empty((B * T * Hh * W, 8), act16(), x)
         H.video_normalize_u8_ndhwc(x, cur, mean, std)
     else:
         B, _, T, Hh, W = x.shape
-        cur = L.empty((B * T * Hh * W, 8), bf16, x)
+        cur = L.empty((B * T * Hh * W, 8), act16(), x)
         H.video_normalize_ndhwc(x, cur, mean, std)
     return run_plan(net.units(), cur, (T, Hh, W), B, training, save, first=True)
 
 
 def run_plan(plan, cur, thw, B, training, save, first=False):
-    """Run a (partial) unit plan on a channels-last bf16 activation [B*T*H*W][Cp]."""
+    """Run a (partial) unit plan on a channels-last 16-bit activation [B*T*H*W][Cp]."""
     tape = []
     block_in = block_thw = None
 
@@ -247,7 +247,7 @@ def run_plan(plan, cur, thw, B, training, save, first=False):
             T, Hh, W = thw
             Cp = cur.shape[1]
             Ho, Wo = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
-            out = L.empty((B * T * Ho * Wo, Cp), bf16, cur)
+            out = L.empty((B * T * Ho * Wo, Cp), act16(), cur)
             H.maxpool3x3s2_fwd(cur, out, B * T, Hh, W, Cp)
             tape.append(("maxpool", (cur, B * T, Hh, W, Cp) if save else None))
             cur, thw = out, (T, Ho, Wo)
@@ -304,7 +304,7 @@ def ensure_streams(device):
 
 
 def trunk_backward(tape, dz, grads, overlap_wgrad=True):
-    """dz bf16 grad of the trunk output; fills `grads[param] = tensor`.
+    """dz 16-bit grad of the trunk output; fills `grads[param] = tensor`.
 
     The weight gradient of a unit is off the critical chain (dz -> BN backward -> dy -> data gradient -> next
     unit), so it is issued on a side stream: the MFMA/latency-bound wgrad kernels then overlap the HBM-bound
@@ -341,7 +341,7 @@ def trunk_backward(tape, dz, grads, overlap_wgrad=True):
             i -= 1
         elif kind == "maxpool":
             x, N, Hh, W, Cp = tape[i][1]
-            dx = L.empty(x.shape, bf16, x)
+            dx = L.empty(x.shape, act16(), x)
             H.maxpool3x3s2_bwd(x, cur, dx, N, Hh, W, Cp)
             cur = dx
             i -= 1

@@ -97,8 +97,13 @@ def test_config_errors_and_yaml_files():
     bad["audio"]["pooling"] = "max"
     with pytest.raises(ValueError, match="Invalid pooling"):
         pig.models.PeppaPig(bad)
-    with pytest.raises(RuntimeError, match="fairseq"):
+    # pretrained: true cannot be honoured offline and must not silently become random init
+    with pytest.raises(RuntimeError, match="Kinetics"):
         pig.models.PeppaPig(copy.deepcopy(default_config))
+    only_audio = copy.deepcopy(default_config)
+    only_audio["video"]["pretrained"] = False
+    with pytest.raises(RuntimeError, match="fairseq"):
+        pig.models.PeppaPig(only_audio)
 
 
 def test_bertadam_host_side(golden_dir):

@@ -116,6 +116,31 @@ def test_stem_conv_cin3():
     close(dw, w.grad, name="stem wgrad")
 
 
+def test_basic_stem_conv_3x7x7_cin3():
+    """r3d_18 / mc3_18 `BasicStem`: Conv3d(3, 64, (3,7,7), stride (1,2,2), pad (1,3,3)) -- 147 taps (the tap tables of
+    pp_igemm / pp_wgrad held 128 in round 1, so these two backbones could not run at all)."""
+    g = torch.Generator().manual_seed(11)
+    B, T, Hh, W = 2, 4, 18, 22
+    x = rb(torch.randn(B, 3, T, Hh, W, generator=g))
+    w = rb(torch.randn(64, 3, 3, 7, 7, generator=g) / 21).requires_grad_()
+    y_ref = F.conv3d(x, w, stride=(1, 2, 2), padding=(1, 3, 3))
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    geom = L.ConvGeom(B, (T, Hh, W), 3, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3), in_cstride=8, cg_in=8)
+    xc = to_cl(x, 8)
+    wf, _ = L.prep_conv_weights(w.detach().to(DEV), geom, need_dgrad=False)
+    y, _ = L.conv_fwd(xc, geom, wf, stats=True)
+    dw = L.conv_wgrad(xc, to_cl(dy, geom.out_cstride), geom, w.shape)
+    torch.cuda.synchronize()
+    close(from_cl(y, B, geom.out_thw, 64), y_ref, name="basic stem fwd")
+    close(dw, w.grad, name="basic stem wgrad")
+    with pytest.raises(Exception, match="taps"):     # 3 x 9 x 11 = 297 taps: rejected, not silently wrong
+        bad = L.ConvGeom(1, (3, 12, 12), 3, 16, (3, 9, 11), (1, 1, 1), (1, 4, 5), in_cstride=8, cg_in=8)
+        L.conv_fwd(to_cl(torch.zeros(1, 3, 3, 12, 12), 8), bad, torch.zeros(16, 297, 8, dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(Exception, match="taps"):
+        L.conv_wgrad_raw(to_cl(torch.zeros(1, 3, 3, 12, 12), 8), torch.zeros(432, 16, dtype=torch.bfloat16, device=DEV), bad)
+
+
 @pytest.mark.parametrize("k,s,T", [(3, 2, 41), (2, 2, 30)])
 def test_conv1d_stack_layer(k, s, T):
     """wav2vec2 feature-extractor convs: Conv1d(512,512,k,s) as a strided GEMM + GELU epilogue."""

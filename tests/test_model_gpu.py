@@ -291,7 +291,8 @@ def test_api_surface_and_errors():
 
 
 def test_static_image_encoder_c1_config():
-    """BASELINE configs[0]: hparams_static.yaml, 8x64x64 frames + 1 s @ 16 kHz audio, batch 4."""
+    """BASELINE configs[0]: hparams_static.yaml, 8x64x64 frames + 1 s @ 16 kHz audio, batch 4 -- the reference's own
+    CPU-runnable case, at its full size: embeddings and loss at SURVEY 8d's tolerances, every gradient present."""
     import os
     import yaml
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -301,12 +302,14 @@ def test_static_image_encoder_c1_config():
     ref.train(); net.train()
     batch = synthetic_batch(4, 8, 64, 16000)
     with torch.no_grad():
-        V32 = ref.encode_video(batch.video)
+        V32, A32 = ref.encode_video(batch.video), ref.encode_audio(batch.audio)
+        loss32 = ref.loss(V32, A32).item()
         sd = copy.deepcopy(ref.state_dict())
         with torch.autocast("cpu", dtype=torch.bfloat16):
             V16 = ref.encode_video(batch.video).float()
         ref.load_state_dict(sd)
     gb = batch.to(DEV)
+    bn_state = copy.deepcopy(net.video_encoder.image.state_dict())
     loss = net.training_step(gb, 0)
     loss.backward()
     torch.cuda.synchronize()
@@ -315,13 +318,55 @@ def test_static_image_encoder_c1_config():
     named = dict(net.named_parameters())
     assert all(named[n].grad is not None and torch.isfinite(named[n].grad).all() for n in used)
     assert net.video_encoder.image.fc.weight.grad is None
+    net.video_encoder.image.load_state_dict(bn_state)
     with torch.no_grad():
         Vh = net.encode_video(gb.video).cpu()
-    yard = 1 - F.cosine_similarity(V16, V32, dim=1).min().item()
-    ours = 1 - F.cosine_similarity(Vh, V32, dim=1).min().item()
-    print(f"static video 1-cos: HIP {ours:.5f} vs torch bf16 autocast of the oracle {yard:.5f}")
+        Ah = net.encode_audio(gb.audio).cpu()
+    cos_v = F.cosine_similarity(Vh, V32, dim=1).min().item()
+    cos_a = F.cosine_similarity(Ah, A32, dim=1).min().item()
+    yard = F.cosine_similarity(V16, V32, dim=1).min().item()
+    print(f"static C1: video min cos {cos_v:.6f} (torch bf16 autocast of the oracle {yard:.6f}) max-abs "
+          f"{(Vh - V32).abs().max().item():.5f}; audio min cos {cos_a:.6f} max-abs {(Ah - A32).abs().max().item():.5f}; "
+          f"loss {loss.item():.6f} vs {loss32:.6f}")
     assert (Vh.norm(dim=1) - 1).abs().max() < 1e-4
-    assert ours <= 1.5 * yard + 2e-3
+    assert cos_v >= 0.999 and (Vh - V32).abs().max().item() <= 2e-2
+    assert cos_a >= 0.999 and (Ah - A32).abs().max().item() <= 2e-2
+    assert abs(loss.item() - loss32) <= 5e-3
+    assert 1 - cos_v <= 1.5 * (1 - yard) + 2e-4
+
+
+@pytest.mark.parametrize("pooling", ["attention", "average"])
+def test_full_false_conv_features_only(pooling):
+    """`audio.full: false` (pig/models.py:86,105): torchaudio 0.9.1's `extract_features` returns the CONV feature
+    extractor's output (512-d, no transformer), pooled and projected; the transformer is an unused
+    parameter set.  Values and gradients against the oracle."""
+    cfg = make_cfg()
+    cfg["audio"]["full"] = False
+    cfg["audio"]["pooling"] = pooling
+    ref, net = build_pair(cfg)
+    ref.train(); net.train()
+    assert net.audio_encoder.n_features == 512
+    batch = synthetic_batch(4, 4, 32, 16000)
+    R = torch.randn(4, 512, generator=torch.Generator().manual_seed(1))
+    Ar = ref.encode_audio(batch.audio)
+    (Ar * R).sum().backward()
+    A = net.encode_audio(batch.audio.to(DEV))
+    (A * R.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    assert F.cosine_similarity(A.detach().cpu(), Ar.detach(), dim=1).min().item() >= 0.999
+    assert (A.detach().cpu() - Ar.detach()).abs().max().item() <= 2e-2
+    refp = dict(ref.audio_encoder.named_parameters())
+    checked = 0
+    for name, p in net.audio_encoder.named_parameters():
+        pr = refp[name]
+        if pr.grad is None:
+            assert p.grad is None, f"{name}: the transformer is unused with full: false"
+            continue
+        assert p.grad is not None, name
+        if pr.grad.norm() > 1e-6:
+            assert rel(p.grad, pr.grad) <= 0.08, (name, rel(p.grad, pr.grad))
+            checked += 1
+    assert checked >= 8 and net.audio_encoder.audio.encoder.transformer.layers[0].attention.q_proj.weight.grad is None
 
 
 def test_audio_dropout_and_layerdrop_train_mode():
