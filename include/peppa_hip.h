@@ -321,10 +321,10 @@ int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const lo
 
 /* ---- dynamic loss scaling for the fp16 build (what Lightning's native AMP does around `BertAdam.step` under
  *      `precision: 16`, /root/reference/hparams_base.yaml:45; torch.cuda.amp.GradScaler semantics) -------------------- */
-/* g *= inv_scale[0] for every tensor of the list, in place; found_inf[0] = 1.0 if any element is inf / nan (else untouched:
+/* g /= scale[0] (scale read from device memory) for every tensor of the list, in place; found_inf[0] = 1.0 if any element is inf / nan (else untouched:
  * zero it first).  = torch._amp_foreach_non_finite_check_and_unscale_.  Only tl->g and tl->numel are read. */
 int pp_grad_unscale_check(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off, int n_chunks,
-                          int chunk, const float* inv_scale, float* found_inf, pp_stream_t s);
+                          int chunk, const float* scale, float* found_inf, pp_stream_t s);
 /* scale / growth_tracker update after a step (= torch._amp_update_scale_): found_inf -> scale *= backoff, tracker = 0;
  * else tracker += 1 and, once it reaches growth_interval, scale *= growth (kept if the product overflows), tracker = 0. */
 int pp_amp_update_scale(float* scale, int* growth_tracker, const float* found_inf, float growth_factor,

@@ -523,11 +523,13 @@ class Wav2Vec2Fn(torch.autograd.Function):
                 H.cast_bf16_to_f32(feat, res)
                 result = res.view(B, T, 512)
         ctx.model, ctx.full, ctx.fe_tape, ctx.enc_tape, ctx.params = model, full, fe_tape, enc_tape, params
+        ctx.precision = H.precision()     # the backward pass runs on the library that produced the tape
         return result
 
     @staticmethod
     def backward(ctx, dout):
         model, grads = ctx.model, grad_dict()
+        H.set_precision(ctx.precision)
         fe = model.feature_extractor
         dout = dout.contiguous().float()
         with torch.no_grad(), L.ZeroPool("audio", dout.device):

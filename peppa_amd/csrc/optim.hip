@@ -92,16 +92,16 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const pp_tensor_list tl, 
   }
 }
 
-// g *= inv_scale; found_inf = 1 on any non-finite element (torch._amp_foreach_non_finite_check_and_unscale_)
+// g /= scale; found_inf = 1 on any non-finite element (torch._amp_foreach_non_finite_check_and_unscale_)
 __global__ __launch_bounds__(256) void unscale_check_kernel(const pp_tensor_list tl, const int* __restrict__ chunk_tensor,
                                                             const long long* __restrict__ chunk_off, int chunk,
-                                                            const float* __restrict__ inv_scale, float* found_inf) {
+                                                            const float* __restrict__ scale, float* found_inf) {
   const int t = chunk_tensor[blockIdx.x];
   const long long off = chunk_off[blockIdx.x];
   const long long n = tl.numel[t];
   float* g = (float*)tl.g[t];
   const long long end = off + chunk < n ? off + chunk : n;
-  const float k = inv_scale[0];
+  const float k = 1.f / scale[0];
   bool bad = false;
   long long done = off;
   if (aligned16(g, g, g, g)) {
@@ -143,10 +143,10 @@ __global__ void amp_update_scale_kernel(float* scale, int* tracker, const float*
 }  // namespace
 
 extern "C" int pp_grad_unscale_check(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off, int n_chunks,
-                                     int chunk, const float* inv_scale, float* found_inf, pp_stream_t s) {
-  PP_CHECK_ARG(tl && tl->n_tensors > 0 && n_chunks > 0 && chunk > 0 && inv_scale && found_inf, "pp_grad_unscale_check: bad arguments");
+                                     int chunk, const float* scale, float* found_inf, pp_stream_t s) {
+  PP_CHECK_ARG(tl && tl->n_tensors > 0 && n_chunks > 0 && chunk > 0 && scale && found_inf, "pp_grad_unscale_check: bad arguments");
   hipLaunchKernelGGL(unscale_check_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)s, *tl, chunk_tensor, chunk_off, chunk,
-                     inv_scale, found_inf);
+                     scale, found_inf);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

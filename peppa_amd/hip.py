@@ -481,6 +481,16 @@ def bertadam_step(tl, chunk_tensor, chunk_off, n_chunks, chunk, norms, lr, b1, b
          _p(norms, f32), lr, b1, b2, eps, wd, max_norm, _p(lr_t, f32), _s())
 
 
+def grad_unscale_check(tl, chunk_tensor, chunk_off, n_chunks, chunk, scale, found_inf):
+    call("pp_grad_unscale_check", C.byref(tl), _p(chunk_tensor, torch.int32), _p(chunk_off, torch.int64), n_chunks, chunk,
+         _p(scale, f32), _p(found_inf, f32), _s())
+
+
+def amp_update_scale(scale, tracker, found_inf, growth, backoff, interval):
+    call("pp_amp_update_scale", _p(scale, f32), _p(tracker, torch.int32), _p(found_inf, f32), float(growth), float(backoff),
+         int(interval), _s())
+
+
 def make_tensor_list(ps, gs, ms, vs, device):
     """Device-resident pointer tables for pp_bertadam_step; returns (TensorList, keepalive)."""
     n = len(ps)

@@ -286,12 +286,14 @@ class VideoTrunkFn(torch.autograd.Function):
         else:
             out, tape, dims = _video_trunk_launch(enc, x, save)
         ctx.tape, ctx.params, ctx.dims = tape, params, dims
+        ctx.precision = H.precision()     # the backward pass runs on the library that produced the tape
         return out
 
     @staticmethod
     def backward(ctx, dout):
         B, Tn, HW, Cp = ctx.dims
         grads = grad_dict()
+        H.set_precision(ctx.precision)
         with torch.no_grad():
             dz = torch.empty(B * Tn * HW, Cp, dtype=act16(), device=dout.device)
             H.spatial_mean_bwd(dout.contiguous().float(), dz, B, Tn, HW, 512, Cp)
@@ -407,8 +409,13 @@ class PeppaPig(_Base):
         self.audio_encoder = Wav2VecEncoder(**config['audio'], weights=extra.get('audio_weights'))
         self._logged = {}
         # optional `mi355x:` block (ignored by the reference): run the two encoders on separate HIP streams
-        self._overlap = bool(config.get('mi355x', {}).get('overlap_encoders', True))
+        self._overlap = bool(extra.get('overlap_encoders', True))
         self._side_stream = None
+        # 16-bit operand type of the towers: "bf16" (default; BASELINE configs[1]) or "fp16" (the reference's own
+        # `precision: 16` AMP, hparams_base.yaml:45; BASELINE configs[4]) -- needs peppa_amd.amp.GradScaler around the
+        # optimizer like any fp16 AMP run.  `Trainer(precision=...)` / run.py --precision set it too.
+        self.precision = "bf16"
+        self.set_precision(extra.get('dtype', 'bf16'))
 
     if pl is None:
         def log(self, name, value, **kwargs):
@@ -431,16 +438,26 @@ class PeppaPig(_Base):
         return ClipBatch(video=V_, audio=A_, video_duration=batch.video_duration,
                          audio_duration=batch.audio_duration)
 
+    def set_precision(self, precision):
+        """"bf16" or "fp16": which build of the HIP library the towers run on from now on."""
+        prev = H.set_precision(precision)
+        self.precision = H.precision()
+        H.set_precision(prev)
+        return self
+
     def encode_video(self, x):
+        H.set_precision(self.precision)
         return self.video_encoder(x)
 
     def encode_audio(self, x):
+        H.set_precision(self.precision)
         return self.audio_encoder(x)
 
     def encode_pair(self, video, audio):
         """Both encoders; they are independent until the loss, so the audio tower (many small
         kernels) runs on a side stream under the video trunk's large ones.  Autograd replays each
         backward on its forward stream, so the overlap also holds for the backward pass."""
+        H.set_precision(self.precision)
         if not (self._overlap and video.is_cuda):
             return self.encode_video(video), self.encode_audio(audio)
         main = torch.cuda.current_stream()

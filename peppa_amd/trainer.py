@@ -40,7 +40,11 @@ class SyntheticPigData:
 class Trainer:
     def __init__(self, accumulate_grad_batches=1, limit_train_batches=None, max_steps=None, max_time_s=None,
                  log_every=10, max_epochs=1, limit_val_batches=None, callbacks=(), default_root_dir=None,
-                 resume_from_checkpoint=None, **ignored):
+                 resume_from_checkpoint=None, precision=None, **ignored):
+        # precision: None / 16 / "bf16" -> the model's own setting (bf16 unless `mi355x: {dtype: fp16}`);
+        # "fp16" -> IEEE half like the reference's AMP runs, with dynamic loss scaling (peppa_amd.amp.GradScaler)
+        self.precision = None if precision in (None, 16, "16") else str(precision)
+        self.scaler = None
         self.accumulate = max(1, int(accumulate_grad_batches))
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.max_steps, self.max_time_s, self.log_every = max_steps, max_time_s, log_every
@@ -74,6 +78,11 @@ class Trainer:
 
     def fit(self, net, data):
         optim = self.optimizer = net.configure_optimizers()
+        if self.precision is not None and hasattr(net, "set_precision"):
+            net.set_precision(self.precision)
+        if getattr(net, "precision", "bf16") == "fp16":
+            from .amp import GradScaler
+            self.scaler = GradScaler()
         buckets = None
         if is_dist():
             buckets = default_buckets(net, next(net.parameters()).device)
@@ -136,12 +145,19 @@ class Trainer:
             if buckets is not None:
                 buckets.sync = stepping
             loss = net.training_step(batch, i)
-            (loss / self.accumulate).backward()
+            if self.scaler is not None:
+                self.scaler.scale(loss / self.accumulate).backward()
+            else:
+                (loss / self.accumulate).backward()
             i += 1
             if stepping:
                 if buckets is not None:
                     buckets.finish()
-                optim.step()
+                if self.scaler is not None:     # unscale (after the all-reduce: every rank sees the same overflow), step or skip
+                    self.scaler.step(optim)
+                    self.scaler.update()
+                else:
+                    optim.step()
                 optim.zero_grad(set_to_none=True)
                 self.global_step += 1
                 if self.global_step % self.log_every == 0:

@@ -56,8 +56,8 @@ def main(args):
     for key in ('accumulate_grad_batches', 'precision'):          # Trainer flags on the command line win (run.py:59-61)
         if getattr(args, key, None) is not None:
             targs[key] = getattr(args, key)
-    if str(targs.get('precision', 16)) not in ('16', 'bf16'):
-        raise SystemExit(f"precision {targs['precision']}: the HIP path computes in 16-bit (bf16 operands, fp32 accumulate)")
+    if str(targs.get('precision', 16)) not in ('16', 'bf16', 'fp16'):
+        raise SystemExit(f"precision {targs['precision']}: the HIP path computes in 16-bit (bf16 or fp16 operands, fp32 accumulate)")
     # the reference's two checkpoint callbacks (run.py:32-55): best epoch by narration recall@10 and by triplet accuracy
     callbacks = [ModelCheckpoint(monitor=monitor, mode='max', save_last=True, save_top_k=1,
                                  filename="{epoch}-{" + monitor + ":.2f}")
@@ -66,7 +66,7 @@ def main(args):
                       limit_train_batches=args.limit_train_batches, limit_val_batches=args.limit_val_batches,
                       max_epochs=args.max_epochs, max_steps=args.max_steps, callbacks=callbacks,
                       default_root_dir=args.default_root_dir, resume_from_checkpoint=args.resume_from_checkpoint,
-                      log_every=args.log_every_n_steps, max_time_s=2 * 24 * 3600)
+                      log_every=args.log_every_n_steps, max_time_s=2 * 24 * 3600, precision=targs.get('precision'))
     trainer.fit(net, data)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -83,7 +83,9 @@ if __name__ == '__main__':
                         help="write Lightning-format checkpoints under {dir}/checkpoints after each validation pass")
     parser.add_argument("--max_steps", type=int, default=None)
     parser.add_argument("--accumulate_grad_batches", type=int, default=None)
-    parser.add_argument("--precision", default=None)
+    parser.add_argument("--precision", default=None,
+                        help="16 / bf16: bf16 operands (default on MI355X); fp16: IEEE half + dynamic loss scaling, as the "
+                             "reference's AMP runs")
     parser.add_argument("--gpus", default=None, help="ignored: one process per GPU (torchrun sets WORLD_SIZE / LOCAL_RANK)")
     parser.add_argument("--resume_from_checkpoint", default=None)
     parser.add_argument("--log_every_n_steps", type=int, default=10)

@@ -56,7 +56,7 @@ def to_cl(x, cp):
     y = x.permute(0, 2, 3, 4, 1).reshape(-1, C)
     out = torch.zeros(y.shape[0], cp)
     out[:, :C] = y
-    return out.to(torch.bfloat16).cuda()
+    return out.to(H.act16()).cuda()
 
 
 def make_cfg(version="r2plus1d_18", static=False):
@@ -86,7 +86,7 @@ def build_pair(cfg, seed=0):
 def blocks_teacher_forced(rv, hv, x0, B, log=print):
     """Every residual block with the ORACLE's activation as input and a fixed random output gradient: isolates the
     kernels chosen at this geometry from the depth effect.  Returns [(name, fwd, dx, worst dW)]."""
-    rb = lambda t: t.to(torch.bfloat16).float()
+    rb = lambda t: t.to(H.act16()).float()
     g = torch.Generator().manual_seed(5)
     x = x0
     rows = []
@@ -117,10 +117,20 @@ def blocks_teacher_forced(rv, hv, x0, B, log=print):
 
 
 def report(batch=8, frames=16, size=112, samples=36800, version="r2plus1d_18", bwd=True, autocast=True, blocks=True,
-           threads=16, log=print):
+           threads=16, log=print, precision="bf16"):
+    """precision: "bf16" | "fp16" -- which build of the HIP library runs (the yardstick stays torch's bf16 autocast)."""
+    prev = H.set_precision(precision)
+    try:
+        return _report(batch, frames, size, samples, version, bwd, autocast, blocks, threads, log, precision)
+    finally:
+        H.set_precision(prev)
+
+
+def _report(batch, frames, size, samples, version, bwd, autocast, blocks, threads, log, precision):
     torch.set_num_threads(threads)
     cfg = make_cfg(version)
     ref, net = build_pair(cfg)
+    net.set_precision(precision)
     data = synthetic_batch(batch, frames, size, samples)
     B = batch
     rv, hv = ref.video_encoder.video, net.video_encoder.video
@@ -168,7 +178,7 @@ def report(batch=8, frames=16, size=112, samples=36800, version="r2plus1d_18", b
     # HIP, stage by stage (free running)
     with torch.no_grad():
         x = gb.video
-        cur = torch.empty(x.numel() // 3, 8, dtype=torch.bfloat16, device="cuda")
+        cur = torch.empty(x.numel() // 3, 8, dtype=H.act16(), device="cuda")
         H.video_normalize_ndhwc(x, cur, *PV.VIDEO_STATS["peppa"])
         thw = tuple(x.shape[2:])
         cur, thw, _ = PV.run_plan(hv.stem_plan(), cur, thw, B, True, False, first=True)
@@ -320,13 +330,14 @@ def main():
     ap.add_argument("--triplets", action="store_true")
     ap.add_argument("--clips", type=int, default=128)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--precision", default="bf16")
     args = ap.parse_args()
     log = lambda *a: print(*a, flush=True)
     if args.triplets:
         triplet_flips(args.clips, frames=args.frames, size=args.size, samples=args.samples, threads=args.threads, log=log)
     else:
         report(args.batch, args.frames, args.size, args.samples, args.version, not args.no_bwd, not args.no_autocast,
-               not args.no_blocks, args.threads, log)
+               not args.no_blocks, args.threads, log, args.precision)
 
 
 if __name__ == "__main__":
