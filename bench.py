@@ -25,8 +25,21 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
-GF_TRAIN_PER_PAIR = 340.0e9      # SURVEY 8d / BASELINE.md: 3 x (81.04 + 32.30) GFLOP
-MFMA_BF16_PEAK = 2.5e15          # dense bf16, MI355X_MICROARCH.md
+GF_TRAIN_PER_PAIR = 340.0e9      # SURVEY 8d / BASELINE.md: 3 x (81.04 + 32.30) GFLOP at 16x112x112 + 36 800 samples
+
+
+def train_flops_per_pair(frames, size, samples, frozen_audio=False):
+    """Algorithmic FLOPs of one training step per clip pair: r2plus1d_18 scales with
+    frames x pixels, wav2vec2 with its frame count (229 frames: 65.76 GF; the quadratic attention term is < 2 %)."""
+    T = (samples - 400) // 320 + 1
+    video = 81.04e9 * (frames / 16.0) * (size / 112.0) ** 2
+    audio = {114: 32.30e9, 229: 65.76e9, 49: 13.82e9}.get(T, 32.30e9 * T / 114.0)
+    if frozen_audio:      # hparams_freeze_wav2vec: forward + data gradient through the frozen layers (SURVEY 8d: ~298 GF at C2)
+        return 3 * video + audio + 22.56e9 * (audio / 32.30e9)
+    return 3 * (video + audio)
+
+
+MFMA_BF16_PEAK = 2.5e15          # dense bf16 / fp16 matrix peak, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 
 
@@ -40,6 +53,8 @@ def parse():
     ap.add_argument("--size", type=int, default=112)
     ap.add_argument("--samples", type=int, default=36800)
     ap.add_argument("--config", default=os.path.join(ROOT, "hparams_base.yaml"))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit operand type: bf16 (BASELINE configs[1]) or fp16 + dynamic loss scaling (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="no HIP events inside the timed region (roofline: null)")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -108,6 +123,11 @@ def main():
     cfg["audio"]["pretrained"] = False
     torch.manual_seed(0)
     net = pig.models.PeppaPig(cfg).to(dev).train()
+    net.set_precision(args.dtype)
+    scaler = None
+    if args.dtype == "fp16":      # what Lightning's native AMP does around BertAdam under the reference's `precision: 16`
+        from peppa_amd.amp import GradScaler
+        scaler = GradScaler()
     optim = net.configure_optimizers()
     batch = synthetic_batch(args.batch, args.frames, args.size, args.samples, seed=1234 + rank).to(dev)
     buckets = None
@@ -117,10 +137,17 @@ def main():
     def step(i):
         optim.zero_grad(set_to_none=True)
         loss = net.training_step(batch, i)
-        loss.backward()
+        if scaler is not None:
+            scaler.scale(loss).backward()
+        else:
+            loss.backward()
         if buckets is not None:
             buckets.finish()
-        optim.step()
+        if scaler is not None:
+            scaler.step(optim)
+            scaler.update()
+        else:
+            optim.step()
         return loss
 
     # The last warm-up step times every large GEMM launch to find the dominant kernel family; in the timed region only
@@ -172,7 +199,10 @@ def main():
         ach = flops / secs / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/), when this family was profiled
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(name)
+            for fn in ("r02_traffic.json", "r01_traffic.json"):
+                path = os.path.join(ROOT, "profiles", fn)
+                if traffic is None and os.path.exists(path):
+                    traffic = json.load(open(path)).get(name)
         except Exception:
             pass
         roof_obj = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
@@ -206,15 +236,22 @@ def main():
                 net.loss(*net.encode_pair(batch.video, batch.audio))
             torch.cuda.synchronize()
             fwd_pairs = world * args.batch * nf / (time.perf_counter() - tf0)
+    cfg_name = os.path.basename(args.config)
+    frozen = bool(cfg["audio"].get("freeze_feature_extractor")) and cfg["audio"].get("freeze_encoder_layers") == 12
+    flops_pair = train_flops_per_pair(args.frames, args.size, args.samples, frozen)
+    which = {("hparams_base.yaml", 16, 36800): " (BASELINE configs[1])", ("hparams_freeze_wav2vec.yaml", 16, 36800): " (BASELINE configs[2])",
+             ("hparams_jitter.yaml", 32, 73600): " (BASELINE configs[4] geometry)"}.get((cfg_name, args.frames, args.samples), "")
     out = {
-        "metric": "clip-pairs/sec (A+V encode + triplet loss), hparams_base", "value": round(value, 2),
+        "metric": f"clip-pairs/sec (A+V encode + triplet loss), {cfg_name[:-5] if cfg_name.endswith('.yaml') else cfg_name}",
+        "value": round(value, 2),
         "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"hparams_base.yaml training step, {args.frames}x{args.size}x{args.size} video + "
-                               f"{args.samples / 16000:.1f} s@16kHz audio, batch {args.batch}/GPU (BASELINE configs[1])",
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{cfg_name} training step, {args.frames}x{args.size}x{args.size} video + "
+                               f"{args.samples / 16000:.1f} s@16kHz audio, batch {args.batch}/GPU{which}",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                   "step_tflops": round(GF_TRAIN_PER_PAIR * world * args.batch / (ms * 1e-3) / 1e12, 1),
+                   "gflop_per_pair": round(flops_pair / 1e9, 1),
+                   "step_tflops": round(flops_pair * world * args.batch / (ms * 1e-3) / 1e12, 1),
                    "loss": round(float(loss.item()), 5),
                    "forward_only_pairs_per_s": None if fwd_pairs is None else round(fwd_pairs, 1)},
         "roofline": roof_obj,

@@ -44,6 +44,21 @@ def _batches(world, accumulate):
     return [synthetic_batch(world * B, FRAMES, SIZE, SAMPLES, seed=50 + k) for k in range(accumulate)]
 
 
+def _objective(net, batch, k, world):
+    """The step's loss (value only) and a SMOOTH objective <V_global, Rv> + <A_global, Ra> through the same all-gather:
+    the hinge loss of near-identical random-init embeddings amplifies last-bit differences of V ~100x (tests/
+    test_parity_c2_gpu.py), which would bury a routing error of a few per cent; its own data-parallel arithmetic is
+    checked exactly on the CPU (tests/test_dist_cpu.py)."""
+    from peppa_amd.dist import gather_embeddings
+    g = torch.Generator().manual_seed(900 + k)
+    Rv, Ra = (torch.randn(world * B, 512, generator=g).cuda() for _ in range(2))
+    V, A = net.encode_pair(batch.video, batch.audio)
+    Vg, Ag = gather_embeddings(V, A)
+    with torch.no_grad():
+        loss = net.loss(Vg, Ag).item()
+    return loss, (Vg * Rv).sum() + (Ag * Ra).sum()
+
+
 def _worker(rank, world, port, out, layer_drop, accumulate):
     warnings.filterwarnings("ignore")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -57,9 +72,9 @@ def _worker(rank, world, port, out, layer_drop, accumulate):
         sl = slice(rank * B, (rank + 1) * B)
         local = type(gb)(gb.video[sl].cuda(), gb.audio[sl].cuda(), gb.video_duration[sl], gb.audio_duration[sl])
         buckets.sync = k == accumulate - 1
-        loss = net.training_step(local, k)
-        (loss / accumulate).backward()
-        losses.append(loss.item())
+        loss, obj = _objective(net, local, k, world)
+        (obj / accumulate).backward()
+        losses.append(loss)
     pushed = sum(len(b["pushed"]) for b in buckets.buckets)
     buckets.finish()
     torch.cuda.synchronize()
@@ -83,9 +98,9 @@ def test_two_ranks_match_one_process_on_the_global_batch(tmp_path, layer_drop, a
     net = _net(_cfg(False), layer_drop)
     losses = []
     for k, gb in enumerate(_batches(world, accumulate)):
-        loss = net.training_step(gb.to("cuda"), k)
-        (loss / accumulate).backward()
-        losses.append(loss.item())
+        loss, obj = _objective(net, gb.to("cuda"), k, world)
+        (obj / accumulate).backward()
+        losses.append(loss)
     torch.cuda.synchronize()
     print("losses", losses, got["loss"], "early hand-offs", got["pushed"])
     assert got["pushed"] > 150
@@ -95,15 +110,29 @@ def test_two_ranks_match_one_process_on_the_global_batch(tmp_path, layer_drop, a
     assert set(ref) == set(got["grads"]), set(ref) ^ set(got["grads"])      # same tensors skipped by LayerDrop / unused
     if layer_drop > 0:
         assert len(ref) < sum(1 for _ in net.parameters()) - 2              # (some layer was dropped in both micro-batches or fc)
-    worst = {}
+    # per group: pooled relative error, ratio of the pooled norms, pooled cosine (tensors whose true gradient is ~0,
+    # e.g. k_proj.bias, only count through the pooled figures)
+    acc = {}
     for n, g in ref.items():
-        e = ((got["grads"][n] - g).norm() / (g.norm() + 1e-12)).item()
-        key = ".".join(n.split(".")[:3])
-        if g.norm() > 1e-6:
-            worst[key] = max(worst.get(key, 0.0), e)
-    for k in sorted(worst):
-        print(f"  {k:40s} {worst[k]:.4f}")
-    # the two runs differ only by summation order (SyncBN's all-reduced sums, float atomics); a wrong routing -- a factor
-    # of world, a rank's rows lost, a bucket reduced twice or never -- is an O(1) error
-    assert max(v for k, v in worst.items() if k.startswith("audio_encoder")) <= 0.05, worst
-    assert max(worst.values()) <= 0.35, worst
+        d = got["grads"][n]
+        parts = n.split(".")
+        key = ".".join(parts[:3]) if parts[1] in ("video", "audio") else ".".join(parts[:2])
+        a = acc.setdefault(key, [0.0, 0.0, 0.0, 0.0])
+        a[0] += (d - g).pow(2).sum().item(); a[1] += g.pow(2).sum().item(); a[2] += d.pow(2).sum().item(); a[3] += (d * g).sum().item()
+    stats = {k: ((e / r) ** 0.5, (dd / r) ** 0.5, dg / (r * dd) ** 0.5) for k, (e, r, dd, dg) in acc.items()}
+    for k in sorted(stats):
+        print(f"  {k:40s} rel-err {stats[k][0]:.4f}  norm ratio {stats[k][1]:.4f}  cosine {stats[k][2]:.4f}")
+    # The two runs differ only by summation order (SyncBN's all-reduced fp32 sums vs one process's block sums, float
+    # atomics).  Audio tower and heads are well conditioned: a few 1e-3..1e-2.  The random-init train-mode-BatchNorm video
+    # trunk at this small shape is chaotic in its backward pass (two identical plain steps differ by several per cent,
+    # DESIGN.md "Numerics"): for it the check is the one a routing error cannot pass -- a factor of `world`, a rank's
+    # rows lost, a bucket reduced twice or never change the NORM of a stage's gradient by >= 30 % or decorrelate it.
+    # (measured: audio 0.3-1.1 %, video projection 3.5 %; trunk stages norm ratio 1.002-1.007, cosine 0.78-0.86)
+    gmax = max(r for _, r, _, _ in acc.values())
+    for k, (err, ratio, cos) in stats.items():
+        if acc[k][1] < 1e-8 * gmax:
+            continue      # analytically zero here (the video attention pooling over a single output frame)
+        if k.startswith("video_encoder.video."):
+            assert 0.9 <= ratio <= 1.1 and cos >= 0.5, (k, err, ratio, cos)
+        else:
+            assert err <= 0.06 and 0.97 <= ratio <= 1.03, (k, err, ratio, cos)
