@@ -85,7 +85,18 @@ typedef struct pp_igemm_desc {
   /* optional dropout in the epilogue (bf16 outputs with bias / activation / residual): C = dropout(act(AB + bias)) +
    * residual, with the mask pp_dropout_bf16 would apply to the flat [M][ldc] tensor for the same (p, seed) */
   float drop_p; unsigned drop_seed;
+  /* optional (data gradients): the BatchNorm-backward sums of the layer that CONSUMES this output as its dz, taken in the
+   * epilogue while the tile is still on chip instead of by a separate pass over dz (pp_bn_bwd_reduce):
+   *   g = C * mask,  mask = [ (bnr_z ? bnr_z : bnr_y * scale + shift) > 0 ] if bnr_relu else 1,  xhat = (bnr_y - mean) * rstd
+   *   bnr_partials[t][0][n] = sum_rows g,  bnr_partials[t][1][n] = sum_rows g * xhat   over rows [256 t, 256 t + 256)
+   * bnr_y / bnr_z: bf16 [M][ldc] like C; mean / rstd / scale / shift: fp32 [ldc]; bnr_partials: fp32 [ceil(M/256)][2][ldc].
+   * Only the window kernels implement it: pp_igemm returns PP_BNR_SKIPPED (the product IS computed) when the kernel it
+   * dispatched to does not, and the caller runs pp_bn_bwd_reduce as before. */
+  const void* bnr_y; const void* bnr_z;
+  const float* bnr_mean; const float* bnr_rstd; const float* bnr_scale; const float* bnr_shift;
+  int bnr_relu; float* bnr_partials;
 } pp_igemm_desc;
+#define PP_BNR_SKIPPED 2
 int pp_igemm(const pp_igemm_desc* d, pp_stream_t s);
 
 /* dW[Ni,Kj] += sum_m dY[m,Ni]^T * X_gather[m,Kj]  (weight gradients; fp32 atomics).

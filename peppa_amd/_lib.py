@@ -34,7 +34,9 @@ class IGemmDesc(C.Structure):
         ("c_s0", C.c_longlong), ("c_s1", C.c_longlong), ("bias_s0", C.c_longlong), ("bias_s1", C.c_longlong),
         ("omap", C.c_int), ("Ot", C.c_int), ("Oh", C.c_int), ("Ow", C.c_int), ("os_t", C.c_int), ("os_h", C.c_int),
         ("os_w", C.c_int), ("oo_t", C.c_int), ("oo_h", C.c_int), ("oo_w", C.c_int),
-        ("drop_p", C.c_float), ("drop_seed", C.c_uint)]
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint),
+        ("bnr_y", C.c_void_p), ("bnr_z", C.c_void_p), ("bnr_mean", C.c_void_p), ("bnr_rstd", C.c_void_p),
+        ("bnr_scale", C.c_void_p), ("bnr_shift", C.c_void_p), ("bnr_relu", C.c_int), ("bnr_partials", C.c_void_p)]
 
 
 class WGradDesc(C.Structure):
@@ -159,6 +161,6 @@ def lib(precision=None):
 def call(name, *args):
     h = lib()
     rc = getattr(h, name)(*args)
-    if name not in _NO_STATUS and rc != 0:
+    if name not in _NO_STATUS and rc < 0:
         raise PeppaHipError(f"{name} failed ({rc}): {h.pp_last_error().decode()}")
-    return rc
+    return rc     # 0, or a positive "done, but ..." code (PP_BNR_SKIPPED)

@@ -715,6 +715,11 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   if (d.colstats) PP_CHECK_ARG(!d.bias && d.act == PP_ACT_NONE && !d.residual && !d.Cpre && d.nbatch == 1 && d.ldstat >= d.N,
                                "pp_igemm: colstats needs a plain epilogue (no bias/act/residual/pre) and nbatch 1");
   PP_CHECK_ARG(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.Bt & 15) == 0, "pp_igemm: operands must be 16-byte aligned");
+  if (d.bnr_partials)
+    PP_CHECK_ARG(d.bnr_y && d.bnr_mean && d.bnr_rstd && d.bnr_scale && d.bnr_shift && !d.c_fp32 && !d.omap && d.nbatch == 1 &&
+                     !d.colstats && !d.bias && d.act == PP_ACT_NONE && d.drop_p == 0.f && ((uintptr_t)d.bnr_y & 15) == 0 &&
+                     (!d.bnr_z || ((uintptr_t)d.bnr_z & 15) == 0),
+                 "pp_igemm: the BatchNorm-backward sums need y + mean / rstd / scale / shift and a plain bf16 data-gradient store");
   const int rc = pp_validate_gather(d.g, d.K, "pp_igemm");
   if (rc != PP_OK) return rc;
   if (d.g.mode != PP_DENSE) {
@@ -743,14 +748,19 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
     const int best = c9 <= c8 ? 9 : 8;
     const bool epi_ok = !full || d.g.mode == PP_DENSE || (d.g.mode == PP_CONV_FWD && best == 8);
     const long long tiles = (((long long)d.M + 255) / 256) * ((n16 + best - 1) / best);
-    if (epi_ok && tiles >= pp_opt_ring) return best == 9 ? launch_ring<9>(d, s) : launch_ring<8>(d, s);
+    if (epi_ok && tiles >= pp_opt_ring) {
+      const int r = best == 9 ? launch_ring<9>(d, s) : launch_ring<8>(d, s);
+      return (r == PP_OK && d.bnr_partials) ? PP_BNR_SKIPPED : r;
+    }
   }
+  int r;
   switch (pick_wn(n16)) {
-    case 15: return launch_wn<15>(d, s);
-    case 9: return launch_wn<9>(d, s);
-    case 8: return launch_wn<8>(d, s);
-    case 4: return launch_wn<4>(d, s);
-    case 3: return launch_wn<3>(d, s);
-    default: return launch_wn<2>(d, s);
+    case 15: r = launch_wn<15>(d, s); break;
+    case 9: r = launch_wn<9>(d, s); break;
+    case 8: r = launch_wn<8>(d, s); break;
+    case 4: r = launch_wn<4>(d, s); break;
+    case 3: r = launch_wn<3>(d, s); break;
+    default: r = launch_wn<2>(d, s); break;
   }
+  return (r == PP_OK && d.bnr_partials) ? PP_BNR_SKIPPED : r;   // (these kernels do not take the BatchNorm-backward sums)
 }

@@ -71,6 +71,12 @@ struct WinArgs {
   const h16raw* residual;
   float* colstats;
   int N, b_rows, ldb, ldc, ldr, ldstat;
+  // BatchNorm-backward sums of the consumer of C, taken in the epilogue (pp_igemm_desc.bnr_*)
+  const h16raw* bnr_y;
+  const h16raw* bnr_z;
+  const float *bnr_mean, *bnr_rstd, *bnr_scale, *bnr_shift;
+  int bnr_relu;
+  float* bnr_partials;
 };
 
 // MT = 16-row tiles per wave (2: 256-row workgroup tile; 4: 512 rows -- narrow outputs, where a weight fragment would
@@ -84,7 +90,10 @@ struct WinArgs {
 // workgroup): its K-steps are short (16 MFMAs per wave with 64 output columns), and re-streaming 8 KB of weights per step
 // from L2 two steps ahead left every step waiting for that DMA.  With resident weights there is no DMA and no barrier
 // inside a phase: one barrier per window.
-template <int WN, int CC, bool RES, int MT, int NBS, bool TW>
+// BNR = the epilogue also accumulates the BatchNorm-backward sums (sum g, sum g * xhat) of the layer that consumes this
+// output as its dz: the tile is in registers / LDS anyway, so bn_bwd_reduce's pass over dz (2 B per element of HBM
+// traffic, a launch) disappears; its read of y moves here.
+template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false>
 __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap) {
   constexpr int BM = 16 * MT * NW;
@@ -293,6 +302,38 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     const int m_wave = mb_e * BM + wave * (16 * MT);
     unsigned char* stg = ebuf + wave * 16 * STG_STRIDE;
     unsigned char* stg_w = stg + (fq * 4) * STG_STRIDE + fr * 2;
+    // BNR: a lane keeps ONE 8-column chunk for the whole tile (RPI rows in flight per wave pass), so that its sixteen
+    // running sums and the chunk's BatchNorm parameters live in registers; otherwise chunks are dealt lane-linearly
+    constexpr int CPR = 2 * WN;                       // 8-column chunks per staged row
+    constexpr int RPI = 64 / CPR;                     // rows per pass with a fixed chunk per lane
+    constexpr int NIT = BNR ? (16 + RPI - 1) / RPI : (32 * WN + 63) / 64;
+    const int b_rsub = lane / CPR, b_ch = lane % CPR;
+    float s1[8], s2[8], mu[8], rs[8], sc[8], sh[8];
+    // the consumer's y chunks of the WHOLE tile are requested up front (MT x NIT 16-byte loads per lane in flight): read
+    // one by one where they are used, every chunk exposed a full HBM round trip inside an epilogue nothing overlaps
+    // (measured: the step 2.8 ms slower with the sums fused than with the separate pp_bn_bwd_reduce pass)
+    uint4 ypre[BNR ? MT * NIT : 1];
+    if (BNR) {
+      const int c0 = nb_e * BN + b_ch * 8;
+      const bool cok = b_rsub < RPI && c0 < ncols_store;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int row = b_rsub + RPI * it;
+          const bool live = cok && row < 16;
+          const int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
+          ypre[mt * NIT + it] = (live && m < g.M) ? *(const uint4*)(p.bnr_y + (long long)m * p.ldc + c0) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        s1[q] = 0.f; s2[q] = 0.f;
+        mu[q] = cok ? p.bnr_mean[c0 + q] : 0.f;
+        rs[q] = cok ? p.bnr_rstd[c0 + q] : 0.f;
+        sc[q] = cok ? p.bnr_scale[c0 + q] : 0.f;
+        sh[q] = cok ? p.bnr_shift[c0 + q] : 0.f;
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -302,13 +343,14 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int it = 0; it < (32 * WN + 63) / 64; ++it) {
+      for (int it = 0; it < NIT; ++it) {
         const int cid = lane + 64 * it;
-        const int row = cid / (2 * WN);
-        const int ch = cid % (2 * WN);
-        const int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + row) : m_wave + mt * 16 + row;
+        const int row = BNR ? b_rsub + RPI * it : cid / CPR;
+        const int ch = BNR ? b_ch : cid % CPR;
+        const bool live = BNR ? (b_rsub < RPI && row < 16) : cid < 32 * WN;
+        const int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
         const int col = nb_e * BN + ch * 8;
-        if (cid < 32 * WN && m < g.M && col < ncols_store) {
+        if (live && m < g.M && col < ncols_store) {
           u32x4 vv;   // (inline asm: a plain LDS load here makes hipcc drain the DMAs in flight, see igemm.hip)
           const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(stg + row * STG_STRIDE + ch * 16);
           asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vv) : "v"(a) : "memory");
@@ -323,10 +365,69 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
             v = pack8(x);
           }
           *(uint4*)(p.C + (long long)m * p.ldc + col) = v;
+          if (BNR) {   // the sums use the bf16 value just stored: exactly what pp_bn_bwd_reduce would read back as dz
+            float d[8], yy[8], zz[8];
+            unpack8(v, d);
+            unpack8(ypre[mt * NIT + it], yy);
+            if (p.bnr_relu) {
+              if (p.bnr_z) unpack8(*(const uint4*)(p.bnr_z + (long long)m * p.ldc + col), zz);
+              else
+#pragma unroll
+                for (int q = 0; q < 8; ++q) zz[q] = yy[q] * sc[q] + sh[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const float gq = (p.bnr_relu && !(zz[q] > 0.f)) ? 0.f : d[q];
+              s1[q] += gq;
+              s2[q] += gq * ((yy[q] - mu[q]) * rs[q]);
+            }
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+    }
+    if (BNR) {
+      // lanes b_ch, b_ch + CPR, ... hold partial sums of the same chunk: fold them onto the first; then the eight waves
+      // meet in LDS and every 256 rows of the tile become one partial row (fixed order: deterministic)
+      float* statbuf = (float*)sbuf;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float a = s1[q], b = s2[q];
+        if (CPR == 8) {          // lanes l, l ^ 8 (row rotate by 8 on the VALU), then the four 16-lane rows
+          a += dpp_f<0x128>(a); b += dpp_f<0x128>(b);
+          a = sum_rows4(a); b = sum_rows4(b);
+        } else if (CPR == 16) {
+          a = sum_rows4(a); b = sum_rows4(b);
+        } else {
+          float ta = a, tb = b;
+#pragma unroll
+          for (int r = 1; r < RPI; ++r) { ta += __shfl(a, b_ch + r * CPR); tb += __shfl(b, b_ch + r * CPR); }
+          a = ta; b = tb;
+        }
+        if (lane < CPR) {
+          statbuf[(wave * BN + b_ch * 8 + q) * 2 + 0] = a;
+          statbuf[(wave * BN + b_ch * 8 + q) * 2 + 1] = b;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      constexpr int HALVES = BM / 256, WPH = NW / HALVES;     // 256-row partial blocks per tile, waves per block
+      for (int idx = tid; idx < BN * HALVES; idx += NT) {
+        const int c = idx % BN, h = idx / BN;
+        const int n = nb_e * BN + c;
+        const long long prow = (long long)mb_e * HALVES + h;
+        if (n < p.ldc && prow * 256 < g.M) {
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int w = 0; w < WPH; ++w) {
+            a += statbuf[((WPH * h + w) * BN + c) * 2 + 0];
+            b += statbuf[((WPH * h + w) * BN + c) * 2 + 1];
+          }
+          p.bnr_partials[(prow * 2 + 0) * p.ldc + n] = a;
+          p.bnr_partials[(prow * 2 + 1) * p.ldc + n] = b;
+        }
+      }
     }
     if (MT == 2 && p.colstats) {   // per-column sum / sum of squares per 128 output rows, deterministic (igemm.hip)
       float* statbuf = (float*)sbuf;
@@ -481,6 +582,10 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   }
 }
 
+// (WN, CC, MT, TW) combinations the data gradients of r2plus1d_18 / r3d_18 / mc3_18 / resnet18 dispatch to get the BNR form
+template <int WN, int CC, int MT, bool TW>
+constexpr bool bnr_built() { return TW ? (CC == 64 && WN == 4) : (WN == 4 || WN == 8); }   // (MT x NIT <= 8 chunks of y per lane)
+
 template <int WN, int CC, int MT, int NBS, bool TW = false>
 int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   constexpr int BN = 16 * WN, BM = 16 * MT * NW;
@@ -499,16 +604,27 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   a.A = (const h16raw*)d.A; a.Bt = (const h16raw*)d.Bt; a.C = (h16raw*)d.C; a.residual = (const h16raw*)d.residual;
   a.colstats = d.colstats;
   a.N = d.N; a.b_rows = d.b_rows; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr; a.ldstat = d.ldstat;
+  a.bnr_y = (const h16raw*)d.bnr_y; a.bnr_z = (const h16raw*)d.bnr_z;
+  a.bnr_mean = d.bnr_mean; a.bnr_rstd = d.bnr_rstd; a.bnr_scale = d.bnr_scale; a.bnr_shift = d.bnr_shift;
+  a.bnr_relu = d.bnr_relu; a.bnr_partials = d.bnr_partials;
   const int nblk_n = (d.N + BN - 1) / BN;
   const long long nblk_m = ((long long)d.M + BM - 1) / BM;
   const long long ntiles = nblk_m * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < 256 ? ntiles : 256;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
+  if constexpr (bnr_built<WN, CC, MT, TW>()) {
+    if (d.bnr_partials) {
+      if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+      else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+      PP_LAUNCH_CHECK();
+      return PP_OK;
+    }
+  }
   if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
   else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
   PP_LAUNCH_CHECK();
-  return PP_OK;
+  return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
 }
 
 }  // namespace
@@ -518,8 +634,8 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
 int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
   const pp_gather& g = d.g;
   const bool conv = g.mode == PP_CONV_FWD || g.mode == PP_CONV_DGRAD;
-  // temporal (3,1,1) stride-1 convs with 4, 8 or 16 frames: 256-row tiles = all frames of 64 / 32 / 16 positions
-  const int pb = (g.Gt == 4 || g.Gt == 8 || g.Gt == 16) ? 256 / g.Gt : 0;
+  // temporal (3,1,1) stride-1 convs with 4, 8, 16 or 32 frames: 256-row tiles = all frames of 64 / 32 / 16 / 8 positions
+  const int pb = (g.Gt == 4 || g.Gt == 8 || g.Gt == 16 || g.Gt == 32) ? 256 / g.Gt : 0;
   const bool tw_ok = pp_opt_win_temporal && conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && d.drop_p == 0.f &&
                      !d.Cpre && !d.omap && g.kt == 3 && g.kh == 1 && g.kw == 1 && g.st == 1 && g.sh == 1 && g.sw == 1 &&
                      g.pt == 1 && g.ph == 0 && g.pw == 0 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && pb > 0 &&

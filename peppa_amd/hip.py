@@ -140,7 +140,9 @@ def _wgrad_family(g):
 
 def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NONE, residual=None, ldr=0,
           Cpre=None, colstats=None, ldstat=0, nbatch=1, inner=1, a_s=(0, 0), b_s=(0, 0), c_s=(0, 0),
-          bias_s=(0, 0), omap=None, dropout=None):
+          bias_s=(0, 0), omap=None, dropout=None, bnr=None):
+    """bnr = (y, z or None, mean, rstd, scale, shift, relu, partials): BatchNorm-backward sums of the consumer of Cout taken
+    in the epilogue (pp_igemm_desc.bnr_*).  Returns True when the dispatched kernel took them (else run bn_bwd_reduce)."""
     d = IGemmDesc()
     if dropout is not None and dropout[0] > 0:     # (p, seed): the mask of dropout_bf16 on the flat output
         d.drop_p, d.drop_seed = float(dropout[0]), int(dropout[1]) & 0xffffffff
@@ -159,8 +161,15 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
     if omap is not None:  # ((Ot, Oh, Ow), (scale t,h,w), (offset t,h,w))
         d.omap = 1
         (d.Ot, d.Oh, d.Ow), (d.os_t, d.os_h, d.os_w), (d.oo_t, d.oo_h, d.oo_w) = omap
+    if bnr is not None:
+        y, z, mean, rstd, scale, shift, relu, partials = bnr
+        d.bnr_y, d.bnr_z = _p(y, act16()), _p(z, act16())
+        d.bnr_mean, d.bnr_rstd, d.bnr_scale, d.bnr_shift = _p(mean, f32), _p(rstd, f32), _p(scale, f32), _p(shift, f32)
+        d.bnr_relu, d.bnr_partials = int(relu), _p(partials, f32)
+    rc = []
     _profiled(f"{_igemm_family(g)}<{_MODE_NAMES[g.mode]}> N={N} K={K}", 2.0 * M * N * K * nbatch,
-              lambda: call("pp_igemm", C.byref(d), _s()))
+              lambda: rc.append(call("pp_igemm", C.byref(d), _s())))
+    return bnr is not None and rc[0] == 0
 
 
 def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0, dbias=None, dbias_s=0):

@@ -174,14 +174,29 @@ def _conv_dgrad_strided(dy, geom, wd, residual):
     return dx
 
 
-def conv_dgrad(dy, geom, wd, *, residual=None):
-    """dx[Min][in_cstride] = conv^T(dy) (+ residual)."""
+FUSE_BN_BWD_REDUCE = False   # consumer BatchNorm-backward sums in the data-gradient epilogue: built, tested, and OFF -- measured slower
+
+
+def conv_dgrad(dy, geom, wd, *, residual=None, consumer=None):
+    """dx[Min][in_cstride] = conv^T(dy) (+ residual).
+
+    consumer = (y, z or None, BNSaved, relu) of the BatchNorm unit that receives dx as its dz: its backward sums
+    (sum g, sum g * xhat) are then accumulated in the epilogue of the window kernels while the tile is on chip, and
+    `consumer_partials(dx)` hands them to bn_bwd, which skips its own pass over dz."""
     if geom.groups == 1 and max(geom.s) == 2:
         return _conv_dgrad_strided(dy, geom, wd, residual)
     dx = empty((geom.Min, geom.in_cstride), act16(), dy)
     if geom.groups == 1:
-        H.igemm(dy, wd, dx, geom.Min, geom.in_cstride, geom.Kd, geom.g_dgrad(), geom.Kd, geom.in_cstride,
-                b_rows=geom.Ci, residual=residual, ldr=geom.in_cstride)
+        bnr = None
+        if consumer is not None and FUSE_BN_BWD_REDUCE and geom.Min >= 1024:
+            y, z, sv, relu = consumer
+            nblk = (geom.Min + 255) // 256
+            partials = empty((nblk, 2, geom.in_cstride), f32, dy)
+            bnr = (y, z, sv.mean, sv.rstd, sv.scale, sv.shift, relu, partials)
+        fused = H.igemm(dy, wd, dx, geom.Min, geom.in_cstride, geom.Kd, geom.g_dgrad(), geom.Kd, geom.in_cstride,
+                        b_rows=geom.Ci, residual=residual, ldr=geom.in_cstride, bnr=bnr)
+        if fused:
+            dx._bnr = (bnr[-1], nblk)     # rides on the tensor object to the bn_bwd call that receives dx as its dz
     else:
         assert residual is None
         G = geom.groups
@@ -254,9 +269,13 @@ def bn_bwd(dz, y, z, sv, gamma, *, relu, want_dres=False):
     """returns dy, dres (masked dz, for the skip connection), dgamma, dbeta.
     z=None (units without a residual input): the ReLU mask is recomputed from y, saving one stream."""
     M, Cp = y.shape
-    nblk = min(2048, (M + 63) // 64)
-    partials = empty((nblk, 2, Cp), f32, y)
-    H.bn_bwd_reduce(dz, y, z, sv.mean, sv.rstd, sv.scale, sv.shift, relu, partials, nblk, M, Cp)
+    ready = getattr(dz, "_bnr", None)
+    if ready is not None:
+        partials, nblk = ready             # (sum g, sum g * xhat) per 256 rows, from the data-gradient epilogue
+    else:
+        nblk = min(2048, (M + 63) // 64)
+        partials = empty((nblk, 2, Cp), f32, y)
+        H.bn_bwd_reduce(dz, y, z, sv.mean, sv.rstd, sv.scale, sv.shift, relu, partials, nblk, M, Cp)
     dgamma, dbeta = empty((sv.C,), f32, y), empty((sv.C,), f32, y)
     coef = empty((3, Cp), f32, y)
     H.bn_bwd_finalize(partials, nblk, sv.count, sv.C, Cp, gamma, sv.rstd, dgamma, dbeta, coef)

@@ -271,6 +271,9 @@ def prelaunch_video_trunk(enc, x):
     return xc
 
 
+FORCE_WGRAD_SIDE = False   # A/B switch (tools/ab_step.py): weight-gradient side stream even when the towers are paired
+
+
 class VideoTrunkFn(torch.autograd.Function):
     """(B,3,T,H,W) fp32 in [0,1] -> spatial means of the trunk output, (B,T',512) fp32."""
 
@@ -287,6 +290,11 @@ class VideoTrunkFn(torch.autograd.Function):
             out, tape, dims = _video_trunk_launch(enc, x, save)
         ctx.tape, ctx.params, ctx.dims = tape, params, dims
         ctx.precision = H.precision()     # the backward pass runs on the library that produced the tape
+        # With the audio tower running beside this trunk (PeppaPig.encode_pair) the weight gradients stay on the trunk's
+        # own stream: the audio kernels already fill the GPU's idle corners, and a third stream only made every kernel of
+        # the critical chain slower (A/B on one box, full step: 49.7 ms without vs 49.9-50.6 ms with the weight-gradient
+        # stream; the trunk alone: 40.0 vs 38.3 ms, so a lone trunk keeps it)
+        ctx.overlap_wgrad = FORCE_WGRAD_SIDE or not getattr(enc, "_paired", False)
         return out
 
     @staticmethod
@@ -298,7 +306,7 @@ class VideoTrunkFn(torch.autograd.Function):
             dz = torch.empty(B * Tn * HW, Cp, dtype=act16(), device=dout.device)
             H.spatial_mean_bwd(dout.contiguous().float(), dz, B, Tn, HW, 512, Cp)
             with L.ZeroPool("video", dout.device):
-                V.trunk_backward(ctx.tape, dz, grads)
+                V.trunk_backward(ctx.tape, dz, grads, overlap_wgrad=ctx.overlap_wgrad)
         ctx.tape = None
         return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
 
@@ -466,7 +474,11 @@ class PeppaPig(_Base):
         video = prelaunch_video_trunk(self.video_encoder, video)  # long kernels first: the host runs ahead of them
         with torch.cuda.stream(side):
             A_ = self.encode_audio(audio)
-        V_ = self.encode_video(video)                            # adopts the launched trunk; node created after audio
+        self.video_encoder._paired = True
+        try:
+            V_ = self.encode_video(video)                        # adopts the launched trunk; node created after audio
+        finally:
+            self.video_encoder._paired = False
         main.wait_stream(side)
         A_.record_stream(main)
         return V_, A_

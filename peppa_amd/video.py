@@ -312,7 +312,7 @@ def trunk_backward(tape, dz, grads, overlap_wgrad=True):
     main = torch.cuda.current_stream()
     side = _wgrad_stream(dz.device) if (overlap_wgrad and OVERLAP_WGRAD) else None
 
-    def unit_bwd(rec, dz_in, relu, want_dres, dgrad_residual=None, need_dx=True):
+    def unit_bwd(rec, dz_in, relu, want_dres, dgrad_residual=None, need_dx=True, consumer=None):
         # units without a residual input recompute the ReLU mask from y (rec.has_res False -> z not read)
         dy, dres, dg, db = L.bn_bwd(dz_in, rec.y, rec.z if rec.has_res else None, rec.sv, rec.bn.weight, relu=relu,
                                     want_dres=want_dres)
@@ -329,44 +329,63 @@ def trunk_backward(tape, dz, grads, overlap_wgrad=True):
                 grads[rec.conv.weight] = L.conv_wgrad(rec.x, dy, rec.geom, rec.conv.weight.shape)
         dx = None
         if need_dx and not rec.first:
-            dx = L.conv_dgrad(dy, rec.geom, rec.wd, residual=dgrad_residual)
+            dx = L.conv_dgrad(dy, rec.geom, rec.wd, residual=dgrad_residual, consumer=consumer)
         return dx, dres
 
+    # the main chain in backward execution order: ("unit" | "block_last" | "block_first" | "maxpool", payload...)
+    items = []
     i = len(tape) - 1
-    cur = dz
     while i >= 0:
         kind = tape[i][0]
         if kind == "unit":
-            cur, _ = unit_bwd(tape[i][1], cur, tape[i][1].relu, False)
+            items.append(("unit", tape[i][1]))
             i -= 1
         elif kind == "maxpool":
-            x, N, Hh, W, Cp = tape[i][1]
-            dx = L.empty(x.shape, act16(), x)
-            H.maxpool3x3s2_bwd(x, cur, dx, N, Hh, W, Cp)
-            cur = dx
+            items.append(("maxpool", tape[i][1]))
             i -= 1
         elif kind == "block_last":
             _, rec, ds_rec = tape[i]
-            # find this block's inner units (between block_begin and here)
             j = i - 1
             inner = []
             while tape[j][0] != "block_begin":
                 inner.append(tape[j][1])
                 j -= 1
-            dmain, dres = unit_bwd(rec, cur, True, True)
-            for r in inner[:-1]:
-                dmain, _ = unit_bwd(r, dmain, r.relu, False)
-            skip = dres
-            if ds_rec is not None:
-                skip, _ = unit_bwd(ds_rec, dres, False, False)
-            firstu = inner[-1] if inner else None
-            if firstu is not None:
-                cur, _ = unit_bwd(firstu, dmain, firstu.relu, False, dgrad_residual=skip)
-            else:
+            if not inner:
                 raise RuntimeError("block without inner units")
+            items.append(("block_last", rec, ds_rec))
+            items += [("unit", r) for r in inner[:-1]]
+            items.append(("block_first", inner[-1]))
             i = j - 1
         else:
             i -= 1
+
+    def consumer_of(k):
+        """The BatchNorm unit that receives item k's data gradient as its dz: (y, z or None, saved statistics, relu) --
+        the window data-gradient kernels take its backward sums in their epilogue (layers.conv_dgrad)."""
+        if k + 1 >= len(items) or items[k + 1][0] == "maxpool":
+            return None
+        nxt = items[k + 1]
+        r = nxt[1]
+        return (r.y, r.z if r.has_res else None, r.sv, True if nxt[0] == "block_last" else r.relu)
+
+    cur, skip = dz, None
+    for k, item in enumerate(items):
+        kind = item[0]
+        if kind == "unit":
+            cur, _ = unit_bwd(item[1], cur, item[1].relu, False, consumer=consumer_of(k))
+        elif kind == "maxpool":
+            x, N, Hh, W, Cp = item[1]
+            dx = L.empty(x.shape, act16(), x)
+            H.maxpool3x3s2_bwd(x, cur, dx, N, Hh, W, Cp)
+            cur = dx
+        elif kind == "block_last":
+            _, rec, ds_rec = item
+            cur, skip = unit_bwd(rec, cur, True, True, consumer=consumer_of(k))
+            if ds_rec is not None:
+                skip, _ = unit_bwd(ds_rec, skip, False, False)
+        else:  # block_first: the skip connection's gradient joins in the data-gradient epilogue
+            cur, _ = unit_bwd(item[1], cur, item[1].relu, False, dgrad_residual=skip, consumer=consumer_of(k))
+            skip = None
     if side is not None:
         main.wait_stream(side)   # every weight gradient is complete before autograd hands them on
     return cur

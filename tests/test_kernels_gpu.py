@@ -846,12 +846,14 @@ def test_window_igemm_matches_gather_igemm(case):
 
 
 @pytest.mark.parametrize("case", [
-    # Ci, Co, B, T, H, W  -- (3,1,1) stride-1 pad-(1,0,0) convs with 4 / 8 / 16 frames: tiles = all frames x positions
+    # Ci, Co, B, T, H, W  -- (3,1,1) stride-1 pad-(1,0,0) convs with 4 / 8 / 16 / 32 frames: tiles = all frames x positions
     (144, 64, 2, 16, 8, 8),       # layer-1 temporal: fwd from three 48-channel chunks, dgrad 64 -> 144 columns
     (45, 64, 3, 16, 4, 12),       # stem: 45 (48) input channels; dgrad to 45 of 48 columns; three clips
     (144, 64, 1, 8, 8, 12),       # 8 frames: 32 positions per tile
     (64, 64, 2, 4, 8, 8),         # 4 frames: 64 positions per tile; 64-channel chunks both ways
     (144, 64, 1, 16, 56, 56),     # layer-1 frame size (196 tiles per clip)
+    (144, 64, 2, 32, 8, 12),      # 32 frames (BASELINE configs[4] clips): 8 positions per tile
+    (45, 64, 1, 32, 4, 14),       # stem at 32 frames
 ])
 def test_temporal_window_igemm_matches_gather_igemm(case):
     """Window kernel in its temporal form (tile = every frame of a block of positions, taps = +-block rows, frames -1
@@ -892,6 +894,67 @@ def test_temporal_window_igemm_matches_gather_igemm(case):
     yr.backward(dyf.to(torch.bfloat16).float())
     close(from_cl(outs[1][0].to(torch.bfloat16), B, (T, Hh, W), Co), yr.detach(), name="temporal window fwd vs torch")
     close(from_cl(outs[1][2].to(torch.bfloat16), B, (T, Hh, W), Ci), xr.grad, name="temporal window dgrad vs torch")
+
+
+@pytest.mark.parametrize("case", [
+    # Ci, Co, k, p, B, T, H, W, with_residual, with_z     (data gradient Co -> Ci; the consumer's BatchNorm has Ci channels)
+    (64, 144, (1, 3, 3), (0, 1, 1), 2, 3, 20, 22, False, False),    # spatial window, 64 columns, 512-row tiles when forced
+    (64, 144, (1, 3, 3), (0, 1, 1), 2, 3, 20, 22, True, True),      # ... with the skip gradient added and the mask taken from z
+    (128, 288, (1, 3, 3), (0, 1, 1), 1, 2, 28, 28, False, False),   # 128 columns (WN = 8), 48-channel chunks
+    (256, 576, (1, 3, 3), (0, 1, 1), 4, 2, 14, 14, True, False),    # 256 columns: two column blocks per row tile
+    (64, 64, (3, 1, 1), (1, 0, 0), 2, 8, 8, 16, False, False),      # temporal window, 64 columns
+    (45, 64, (3, 1, 1), (1, 0, 0), 2, 16, 4, 12, False, False),     # temporal window, 45 of 48 columns
+    (64, 230, (1, 3, 3), (0, 1, 1), 1, 3, 9, 56, True, True),       # ragged last tile
+])
+@pytest.mark.parametrize("tall", [0, 2])
+def test_bn_backward_sums_in_the_dgrad_epilogue(case, tall):
+    """pp_igemm_desc.bnr_*: the window data-gradient kernels accumulate sum g and sum g * xhat of the BatchNorm layer that
+    receives their output as dz; the sums must equal those pp_bn_bwd_reduce takes from the stored dz."""
+    Ci, Co, k, p, B, T, Hh, W, with_res, with_z = case
+    g = torch.Generator().manual_seed(Ci + 3 * Co + T)
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, (1, 1, 1), p)
+    dy = to_cl(rb(torch.randn(B, Co, T, Hh, W, generator=g)), geom.out_cstride)
+    w = rb(torch.randn(Co, Ci, *k, generator=g) / math.sqrt(Ci * k[0] * k[1] * k[2]))
+    _, wd = L.prep_conv_weights(w.to(DEV).contiguous(), geom)
+    Cp = geom.in_cstride
+    y = to_cl(rb(torch.randn(B, Ci, T, Hh, W, generator=g)), Cp)
+    z = to_cl(rb(torch.randn(B, Ci, T, Hh, W, generator=g)), Cp) if with_z else None
+    res = to_cl(rb(torch.randn(B, Ci, T, Hh, W, generator=g)), Cp) if with_res else None
+    sv = L.BNSaved()
+    sv.count, sv.C, sv.Cp = geom.Min, Ci, Cp
+    pad = lambda t: torch.cat([t, torch.zeros(Cp - Ci)]).to(DEV)
+    sv.mean, sv.rstd = pad(0.3 * torch.randn(Ci, generator=g)), pad(0.5 + torch.rand(Ci, generator=g))
+    sv.scale, sv.shift = pad(torch.randn(Ci, generator=g)), pad(0.3 * torch.randn(Ci, generator=g))
+    try:
+        H.set_option("win_tall", tall)
+        L.FUSE_BN_BWD_REDUCE = True      # (off by default: the fused epilogue measured 0.6 ms per step slower, DESIGN.md)
+        for relu in (True, False):
+            dx = L.conv_dgrad(dy, geom, wd, residual=res, consumer=(y, z, sv, relu))
+            torch.cuda.synchronize()
+            assert hasattr(dx, "_bnr"), "this shape should have taken the fused path"
+            partials, nblk = dx._bnr
+            assert nblk == (geom.Min + 255) // 256 and partials.shape == (nblk, 2, Cp)
+            plain = L.conv_dgrad(dy, geom, wd, residual=res)
+            assert torch.equal(plain, dx), "the product itself must not change"
+            nref = min(2048, (geom.Min + 63) // 64)
+            ref = torch.empty(nref, 2, Cp, device=DEV)
+            H.bn_bwd_reduce(dx, y, z, sv.mean, sv.rstd, sv.scale, sv.shift, relu, ref, nref, geom.Min, Cp)
+            torch.cuda.synchronize()
+            got, want = partials.double().sum(0).cpu(), ref.double().sum(0).cpu()
+            scale = want.abs().max().item()
+            assert (got - want).abs().max().item() <= 2e-5 * scale + 1e-4, (relu, (got - want).abs().max().item(), scale)
+            assert (got[:, Ci:] == 0).all()
+        # a kernel without the epilogue says so and the caller falls back (strided / grouped / tiny problems)
+        small = L.ConvGeom(32, (2, 6, 6), 32, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        _, wds = L.prep_conv_weights(torch.randn(48, 32, 3, 3, 3, device=DEV), small)
+        ys = to_cl(torch.randn(32, 32, 2, 6, 6), small.in_cstride)
+        svs = L.BNSaved()
+        svs.mean = svs.rstd = svs.scale = svs.shift = torch.ones(small.in_cstride, device=DEV)
+        dxs = L.conv_dgrad(to_cl(torch.randn(32, 48, 2, 6, 6), small.out_cstride), small, wds, consumer=(ys, None, svs, True))
+        assert not hasattr(dxs, "_bnr")
+    finally:
+        H.set_option("win_tall", 1)
+        L.FUSE_BN_BWD_REDUCE = False
 
 
 @pytest.mark.parametrize("case", [

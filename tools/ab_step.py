@@ -1,0 +1,65 @@
+"""A/B of step-level switches on ONE box, alternating inside one process (boxes of the pool differ by +-5 %):
+    python tools/ab_step.py fuse_bnr wgrad_side        # each named switch is toggled against the default"""
+import os
+import sys
+import time
+import warnings
+
+warnings.filterwarnings("ignore")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import yaml
+import pig.models
+from peppa_amd import layers as L
+from peppa_amd import video as PV
+from peppa_amd import models as PM
+from peppa_amd.data import synthetic_batch
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cfg = yaml.safe_load(open(os.path.join(root, "hparams_base.yaml")))
+cfg["video"]["pretrained"] = cfg["audio"]["pretrained"] = False
+torch.manual_seed(0)
+net = pig.models.PeppaPig(cfg).cuda().train()
+opt = net.configure_optimizers()
+b = synthetic_batch(64, 16, 112, 36800).to("cuda")
+
+
+def step(i):
+    opt.zero_grad(set_to_none=True)
+    net.training_step(b, i).backward()
+    opt.step()
+
+
+def timed(n=12):
+    step(0); step(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        step(2 + i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+class _Paired:
+    """wgrad_side: the weight-gradient side stream also when the towers are paired (round-1 behaviour)."""
+    orig = PM.VideoTrunkFn.forward
+
+
+def set_switch(name, on):
+    if name == "fuse_bnr":
+        L.FUSE_BN_BWD_REDUCE = on
+    elif name == "wgrad_side":
+        PM.FORCE_WGRAD_SIDE = on
+    else:
+        raise SystemExit(f"unknown switch {name}")
+
+
+defaults = {"fuse_bnr": True, "wgrad_side": False}
+for _ in range(3):
+    step(0)
+for name in sys.argv[1:]:
+    for rep in range(3):
+        for on in (defaults[name], not defaults[name]):
+            set_switch(name, on)
+            print(f"{name}={on}: {timed():.2f} ms/step", flush=True)
+    set_switch(name, defaults[name])

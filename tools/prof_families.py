@@ -1,0 +1,63 @@
+"""Kernel families alone vs in-step: merges the kernel_stats.csv of two rocprofv3 runs of
+tools/step_loop.py -- default (three streams overlapped) and --isolated (one kernel at a time) -- into one markdown table.
+
+    python tools/prof_families.py IN_STEP.csv ISOLATED.csv NSTEPS OUT.md "title"
+"""
+import csv
+import re
+import sys
+
+FAMILIES = [
+    ("window conv fwd/dgrad (igemm_win)", r"igemm_win_kernel"),
+    ("generic / ring implicit GEMM (igemm)", r"igemm_kernel"),
+    ("sliding-window wgrad (wgrad_sw)", r"wgrad_sw_kernel"),
+    ("temporal-window wgrad (wgrad_tw)", r"wgrad_tw_kernel"),
+    ("generic wgrad", r"wgrad_kernel"),
+    ("BatchNorm apply", r"bn_apply_kernel"),
+    ("BatchNorm backward reduce", r"bn_bwd_reduce_kernel"),
+    ("BatchNorm backward apply", r"bn_bwd_apply_kernel"),
+    ("BatchNorm finalize / partials", r"bn_finalize|bn_bwd_finalize|partials_reduce|bn_eval"),
+    ("attention fwd", r"attention_fwd"),
+    ("attention bwd", r"attention_bwd"),
+    ("LayerNorm", r"ln_"),
+    ("wav2vec2 conv0 (+GroupNorm, GELU)", r"conv0_"),
+    ("GELU / dropout / add / transpose", r"gelu|dropout|add_|transpose|colsum|softmax"),
+    ("weight preparation (casts, layouts)", r"prep_conv|unprep_conv|cast_|select_taps|weightnorm|wn_"),
+    ("heads + loss (fp32)", r"sgemm|timepool|l2norm|cosnorm|loss_|hinge|spatial_mean|copy_f32|diag_|gdiag"),
+    ("BertAdam", r"bertadam|sumsq|unscale"),
+    ("input normalise / collate / maxpool", r"video_normalize|collate|maxpool"),
+    ("torch fills / copies", r"at::native|Memset|Memcpy|fill"),
+]
+
+
+def load(path, steps):
+    fam = {}
+    for r in csv.DictReader(open(path)):
+        name = r["Name"]
+        for label, pat in FAMILIES:
+            if re.search(pat, name):
+                break
+        else:
+            label = "other"
+        a = fam.setdefault(label, [0, 0.0])
+        a[0] += int(r["Calls"])
+        a[1] += float(r["TotalDurationNs"])
+    return {k: (c / steps, ns / steps / 1e6) for k, (c, ns) in fam.items()}
+
+
+def main(in_step, isolated, steps, out, title):
+    a, b = load(in_step, steps), load(isolated, steps)
+    ta, tb = sum(v[1] for v in a.values()), sum(v[1] for v in b.values())
+    with open(out, "w") as f:
+        f.write(f"# {title}\n\nsources: `{in_step}` (towers and weight gradients on three streams, as bench.py runs) and "
+                f"`{isolated}` (same step, one stream, one kernel at a time); {steps} steps each, ms per step.\n\n")
+        f.write("| family | launches/step | ms/step alone | ms/step in-step | in-step / alone |\n|---|---|---|---|---|\n")
+        for label in sorted(set(a) | set(b), key=lambda k: -b.get(k, (0, 0))[1]):
+            ca, ma = a.get(label, (0, 0.0))
+            cb, mb = b.get(label, (0, 0.0))
+            f.write(f"| {label} | {max(ca, cb):.1f} | {mb:.2f} | {ma:.2f} | {ma / mb if mb else float('nan'):.2f} |\n")
+        f.write(f"| **total kernel time** | | **{tb:.2f}** | **{ta:.2f}** | {ta / tb:.2f} |\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
