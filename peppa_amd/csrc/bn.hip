@@ -4,7 +4,29 @@
 // Replaces the 37 torch.nn.BatchNorm3d layers of torchvision r2plus1d_18 (pig/models.py:141-150).
 #include "common.h"
 
+extern int pp_opt_bn_nt;     // bit 0: non-temporal loads, bit 1: non-temporal stores in the streaming passes
+extern int pp_opt_bn_grid;   // workgroup cap of the streaming passes
+
 namespace {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const h16raw* p) {
+  if (NT) {
+    const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  }
+  return *(const uint4*)p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(h16raw* p, const uint4 v) {
+  if (NT) {
+    u32x4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (u32x4_t*)p);
+  } else {
+    *(uint4*)p = v;
+  }
+}
 
 // Column-partial reducer: block b handles rows [b*rows_per_blk, ...); thread owns one 8-channel
 // chunk and strides over rows; NACC running sums per channel.
@@ -122,6 +144,7 @@ __device__ __forceinline__ void load8(const float* __restrict__ p, float (&f)[8]
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
+template <bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const h16raw* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const h16raw* __restrict__ res,
                                                        int relu, h16raw* __restrict__ z, long long M, int cpr) {
@@ -150,14 +173,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const h16raw* __restrict_
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   for (; r + stride < M; r += 2 * stride) {
     const long long i0 = (r * cpr + ch) * 8, i1 = ((r + stride) * cpr + ch) * 8;
-    const uint4 v0 = *(const uint4*)(y + i0), v1 = *(const uint4*)(y + i1);
-    const uint4 r0 = res ? *(const uint4*)(res + i0) : zero4, r1 = res ? *(const uint4*)(res + i1) : zero4;
-    *(uint4*)(z + i0) = one(v0, r0);
-    *(uint4*)(z + i1) = one(v1, r1);
+    const uint4 v0 = ld16<NTL>(y + i0), v1 = ld16<NTL>(y + i1);
+    const uint4 r0 = res ? ld16<NTL>(res + i0) : zero4, r1 = res ? ld16<NTL>(res + i1) : zero4;
+    st16<NTS>(z + i0, one(v0, r0));
+    st16<NTS>(z + i1, one(v1, r1));
   }
   if (r < M) {
     const long long i0 = (r * cpr + ch) * 8;
-    *(uint4*)(z + i0) = one(*(const uint4*)(y + i0), res ? *(const uint4*)(res + i0) : zero4);
+    st16<NTS>(z + i0, one(ld16<NTL>(y + i0), res ? ld16<NTL>(res + i0) : zero4));
   }
 }
 
@@ -233,6 +256,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
+template <bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const h16raw* __restrict__ dz, const h16raw* __restrict__ y,
                                                            const h16raw* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ coef,
@@ -268,22 +292,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const h16raw* __restr
       o[q] = k0[q] * (g - k1[q] - xh * k2[q]);
       d[q] = g;
     }
-    *(uint4*)(dy + i) = pack8(o);
-    if (dres) *(uint4*)(dres + i) = pack8(d);
+    st16<NTS>(dy + i, pack8(o));
+    if (dres) st16<NTS>(dres + i, pack8(d));
   };
   const long long stride = (long long)gridDim.x * rpb;
   long long r = (long long)blockIdx.x * rpb + rsub;
   for (; r + stride < M; r += 2 * stride) {
     const long long i0 = (r * cpr + ch) * 8, i1 = ((r + stride) * cpr + ch) * 8;
-    const uint4 d0 = *(const uint4*)(dz + i0), d1 = *(const uint4*)(dz + i1);
-    const uint4 y0 = *(const uint4*)(y + i0), y1 = *(const uint4*)(y + i1);
-    const uint4 z0 = (relu && z) ? *(const uint4*)(z + i0) : zero4, z1 = (relu && z) ? *(const uint4*)(z + i1) : zero4;
+    const uint4 d0 = ld16<NTL>(dz + i0), d1 = ld16<NTL>(dz + i1);
+    const uint4 y0 = ld16<NTL>(y + i0), y1 = ld16<NTL>(y + i1);
+    const uint4 z0 = (relu && z) ? ld16<NTL>(z + i0) : zero4, z1 = (relu && z) ? ld16<NTL>(z + i1) : zero4;
     one(i0, d0, y0, z0);
     one(i1, d1, y1, z1);
   }
   if (r < M) {
     const long long i0 = (r * cpr + ch) * 8;
-    one(i0, *(const uint4*)(dz + i0), *(const uint4*)(y + i0), (relu && z) ? *(const uint4*)(z + i0) : zero4);
+    one(i0, ld16<NTL>(dz + i0), ld16<NTL>(y + i0), (relu && z) ? ld16<NTL>(z + i0) : zero4);
   }
 }
 
@@ -303,7 +327,7 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 
 int stream_grid(long long nchunks) {
   long long b = (nchunks + 255) / 256;
-  if (b > 4096) b = 4096;
+  if (b > pp_opt_bn_grid) b = pp_opt_bn_grid;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -359,8 +383,16 @@ extern "C" int pp_bn_apply(const void* y, const float* scale, const float* shift
                            long long M, int Cp, pp_stream_t s) {
   CHECK_CP(Cp, "pp_bn_apply");
   const long long nchunks = M * (Cp / 8);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const h16raw*)y, scale,
-                     shift, (const h16raw*)res, relu, (h16raw*)z, M, Cp / 8);
+#define LAUNCH_APPLY(NTL, NTS)                                                                                           \
+  hipLaunchKernelGGL((bn_apply_kernel<NTL, NTS>), dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const h16raw*)y, \
+                     scale, shift, (const h16raw*)res, relu, (h16raw*)z, M, Cp / 8)
+  switch (pp_opt_bn_nt & 3) {
+    case 0: LAUNCH_APPLY(false, false); break;
+    case 1: LAUNCH_APPLY(true, false); break;
+    case 2: LAUNCH_APPLY(false, true); break;
+    default: LAUNCH_APPLY(true, true); break;
+  }
+#undef LAUNCH_APPLY
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -392,8 +424,16 @@ extern "C" int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, con
   PP_CHECK_ARG(!relu || z || (scale && shift), "pp_bn_bwd_apply: relu needs z or scale/shift");
   CHECK_CP(Cp, "pp_bn_bwd_apply");
   const long long nchunks = M * (Cp / 8);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const h16raw*)dz,
-                     (const h16raw*)y, (const h16raw*)z, mean, rstd, coef, scale, shift, relu, (h16raw*)dy, (h16raw*)dres, M, Cp / 8, Cp);
+#define LAUNCH_BAPPLY(NTL, NTS)                                                                                                   \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<NTL, NTS>), dim3(stream_grid(nchunks / 2)), dim3(256), 0, (hipStream_t)s, (const h16raw*)dz, \
+                     (const h16raw*)y, (const h16raw*)z, mean, rstd, coef, scale, shift, relu, (h16raw*)dy, (h16raw*)dres, M, Cp / 8, Cp)
+  switch (pp_opt_bn_nt & 3) {
+    case 0: LAUNCH_BAPPLY(false, false); break;
+    case 1: LAUNCH_BAPPLY(true, false); break;
+    case 2: LAUNCH_BAPPLY(false, true); break;
+    default: LAUNCH_BAPPLY(true, true); break;
+  }
+#undef LAUNCH_BAPPLY
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

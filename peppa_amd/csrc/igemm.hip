@@ -24,6 +24,11 @@ int pp_opt_sw_wgrad = 4096;    // sliding-window weight gradient for (1,3,3) str
 int pp_opt_ring_wgrad = 0;      // LDS-DMA ring weight gradient once the reduce dimension has this many rows (0 = never)
 int pp_opt_ring = 128; // LDS-DMA ring variant once there are this many 256-row tiles (0 = never)
 int pp_opt_xcd_remap_wgrad = 1;
+// BatchNorm streaming passes (tools/bench_bn.py, layer-1 shapes): non-temporal STORES + 32 k workgroups instead of plain
+// stores + 4 k: apply 417 -> 370 us, backward apply 576 -> 485 us at 144 channels (4.4 / 4.8 -> 5.0 / 5.7 TB/s); non-temporal
+// loads on top bought nothing.  bit 0: non-temporal loads, bit 1: non-temporal stores.
+int pp_opt_bn_nt = 2;
+int pp_opt_bn_grid = 32768;
 extern "C" int pp_set_option(const char* name, int value) {
   if (!name) return PP_ERR_INVALID;
   if (!strcmp(name, "xcd_remap_igemm")) { pp_opt_xcd_remap_igemm = value; return PP_OK; }
@@ -35,6 +40,8 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "ring_igemm")) { pp_opt_ring = value; return PP_OK; }
   if (!strcmp(name, "persistent_igemm")) { pp_opt_persistent = value; return PP_OK; }
   if (!strcmp(name, "xcd_remap_wgrad")) { pp_opt_xcd_remap_wgrad = value; return PP_OK; }
+  if (!strcmp(name, "bn_nt")) { pp_opt_bn_nt = value; return PP_OK; }
+  if (!strcmp(name, "bn_grid")) { pp_opt_bn_grid = value > 0 ? value : 32768; return PP_OK; }
   pp_set_error("pp_set_option: unknown option %s", name);
   return PP_ERR_INVALID;
 }

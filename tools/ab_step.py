@@ -50,11 +50,15 @@ def set_switch(name, on):
         L.FUSE_BN_BWD_REDUCE = on
     elif name == "wgrad_side":
         PM.FORCE_WGRAD_SIDE = on
+    elif name == "bn_tuned":
+        from peppa_amd import hip as H
+        H.set_option("bn_nt", 2 if on else 0)
+        H.set_option("bn_grid", 32768 if on else 4096)
     else:
         raise SystemExit(f"unknown switch {name}")
 
 
-defaults = {"fuse_bnr": True, "wgrad_side": False}
+defaults = {"fuse_bnr": False, "wgrad_side": False, "bn_tuned": True}
 for _ in range(3):
     step(0)
 for name in sys.argv[1:]:

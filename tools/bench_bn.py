@@ -6,6 +6,10 @@ import torch
 from peppa_amd import hip as H, layers as L
 
 dev = "cuda"
+for opt in ("bn_nt", "bn_grid"):
+    if opt.upper() in os.environ:
+        H.set_option(opt, int(os.environ[opt.upper()]))
+        print(opt, "=", os.environ[opt.upper()])
 
 
 def timeit(fn, n=10):
