@@ -98,8 +98,8 @@ SIGNATURES = {
     "pp_colsum_bf16": [P, L, I, I, P, P],
     "pp_layernorm_fwd": [P, P, P, F, P, P, P, I, I, P],
     "pp_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, P, I, P],
-    "pp_attention_fwd": [P, I, I, I, F, F, C.c_uint, P, P],
-    "pp_attention_bwd": [P, P, I, I, I, F, F, C.c_uint, P, P],
+    "pp_attention_fwd": [P, I, I, I, F, F, C.c_uint, P, P, P],
+    "pp_attention_bwd": [P, P, P, P, I, I, I, F, F, C.c_uint, P, P],
     "pp_softmax_fwd": [P, I, P, I, I, I, F, P],
     "pp_softmax_bwd": [P, I, P, I, P, I, I, F, P],
     "pp_conv0_stats": [P, I, I, I, P, P, P],

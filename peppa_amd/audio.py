@@ -259,17 +259,20 @@ def _prep_encoder_weights(enc, save):
     return w, batch
 
 
-FUSED_ATTENTION = True   # one launch per direction (pp_attention_*) when T <= 128; False: batched GEMMs + softmax + transposes
+FUSED_ATTENTION = True   # one launch per direction (pp_attention_*) when T <= 256; False: batched GEMMs + softmax + transposes
+FUSED_ATTENTION_MAX_T = 256
 
 
 def _attention_fwd(qkv, B, T, Tp, scale, save, drop=(0.0, 0)):
-    """qkv 16-bit [B*T][2304] -> ctx 16-bit [B*T][768]; returns saved P (before attention dropout), or None (fused path:
-    the backward recomputes the probabilities)."""
+    """qkv 16-bit [B*T][2304] -> ctx 16-bit [B*T][768]; returns what the backward pass needs besides qkv and ctx: the saved P
+    (before attention dropout) on the unfused path, the rows' log-sum-exp (fp32 [B*12][T]) on the fused one, which
+    recomputes the probabilities."""
     Hn, Dh, D3 = NUM_HEADS, 64, 2304
-    if FUSED_ATTENTION and T <= 128:
+    if FUSED_ATTENTION and T <= FUSED_ATTENTION_MAX_T:
         ctx = L.empty((B * T, 768), act16(), qkv)
-        H.attention_fwd(qkv, B, T, Hn, scale, drop[0], drop[1], ctx)
-        return ctx, None
+        lse = L.empty((B * Hn, T), f32, qkv)
+        H.attention_fwd(qkv, B, T, Hn, scale, drop[0], drop[1], ctx, lse)
+        return ctx, lse
     nb = B * Hn
     S = L.empty((nb, T, Tp), f32, qkv)
     q, k, v = qkv, qkv[:, 768:], qkv[:, 1536:]   # column views (pointer offsets only)
@@ -289,12 +292,12 @@ def _attention_fwd(qkv, B, T, Tp, scale, save, drop=(0.0, 0)):
     return ctx, (P if save else None)
 
 
-def _attention_bwd(dctx, qkv, P, B, T, Tp, scale, drop=(0.0, 0)):
-    """-> dqkv 16-bit [B*T][2304]."""
+def _attention_bwd(dctx, qkv, ctx, P, B, T, Tp, scale, drop=(0.0, 0)):
+    """-> dqkv 16-bit [B*T][2304].  P: what _attention_fwd returned (fp32 log-sum-exp rows = the fused path)."""
     Hn, Dh, D3 = NUM_HEADS, 64, 2304
-    if P is None:   # forward ran fused
+    if P is not None and P.dtype == f32:   # forward ran fused
         dqkv = L.empty((B * T, D3), act16(), qkv)
-        H.attention_bwd(qkv, dctx, B, T, Hn, scale, drop[0], drop[1], dqkv)
+        H.attention_bwd(qkv, ctx, P, dctx, B, T, Hn, scale, drop[0], drop[1], dqkv)
         return dqkv
     nb = B * Hn
     q, k, v = qkv, qkv[:, 768:], qkv[:, 1536:]
@@ -456,7 +459,7 @@ def _enc_backward(enc, t, dout, grads):
             H.dropout_bf16(ds1, dt1, *r.d_out)
         _lin_grads(grads, att.out_proj, r.ctx, dt1, M, 768, 768)
         dctx = L.linear_dgrad(dt1, M, r.out_wt, 768)
-        dqkv = _attention_bwd(dctx, r.qkv, r.P, B, T, Tp, att.scaling, r.d_att)
+        dqkv = _attention_bwd(dctx, r.qkv, r.ctx, r.P, B, T, Tp, att.scaling, r.d_att)
         # q/k/v projections share one fused weight gradient
         need = any(p.requires_grad for p in (att.q_proj.weight, att.k_proj.weight, att.v_proj.weight))
         if need:

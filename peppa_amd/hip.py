@@ -353,13 +353,14 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, ws=None)
          _p(dgamma, f32), _p(dbeta, f32), rows, D, _p(ws, f32), 0 if ws is None else ws.shape[0], _s())
 
 
-def attention_fwd(qkv, B, T, heads, scale, p, seed, ctx):
-    call("pp_attention_fwd", _p(qkv, act16()), B, T, heads, float(scale), float(p), int(seed) & 0xffffffff, _p(ctx, act16()), _s())
+def attention_fwd(qkv, B, T, heads, scale, p, seed, ctx, lse):
+    call("pp_attention_fwd", _p(qkv, act16()), B, T, heads, float(scale), float(p), int(seed) & 0xffffffff, _p(ctx, act16()),
+         _p(lse, f32), _s())
 
 
-def attention_bwd(qkv, dctx, B, T, heads, scale, p, seed, dqkv):
-    call("pp_attention_bwd", _p(qkv, act16()), _p(dctx, act16()), B, T, heads, float(scale), float(p), int(seed) & 0xffffffff,
-         _p(dqkv, act16()), _s())
+def attention_bwd(qkv, ctx, lse, dctx, B, T, heads, scale, p, seed, dqkv):
+    call("pp_attention_bwd", _p(qkv, act16()), _p(ctx, act16()), _p(lse, f32), _p(dctx, act16()), B, T, heads, float(scale),
+         float(p), int(seed) & 0xffffffff, _p(dqkv, act16()), _s())
 
 
 def softmax_fwd(S, lds, P, ldp, nb, T, scale):

@@ -1041,10 +1041,13 @@ def test_recall_metrics_on_device(golden_dir):
     assert t.shape == (3, 5, 100) and (t[:, 0] == 0).all() and (t[:, 1:].diff(dim=1) >= 0).all()
 
 
-@pytest.mark.parametrize("B,T,p", [(3, 114, 0.0), (2, 49, 0.1), (2, 128, 0.1), (1, 7, 0.0)])
+@pytest.mark.parametrize("B,T,p", [(3, 114, 0.0), (2, 49, 0.1), (2, 128, 0.1), (1, 7, 0.0),
+                                   (2, 229, 0.0), (2, 229, 0.1), (1, 256, 0.1), (1, 129, 0.0), (2, 200, 0.0)])
 def test_fused_attention_matches_unfused_and_torch(B, T, p):
-    """pp_attention_fwd / _bwd (one workgroup per clip and head, scores in MFMA accumulators, probabilities recomputed in
-    the backward) against the unfused HIP path (same dropout stream) and, without dropout, against fp32 torch."""
+    """pp_attention_fwd / _bwd (scores in MFMA accumulators, probabilities recomputed in the backward from the forward's
+    log-sum-exp rows; T <= 128: one workgroup per clip and head, T <= 256 -- the 229 frames of BASELINE configs[4] --
+    64-query-row workgroups forward and 2 x 2 blocks of 128 backward) against the unfused HIP path (same dropout stream)
+    and, without dropout, against fp32 torch."""
     from peppa_amd import audio as A
     g = torch.Generator().manual_seed(B * 100 + T)
     M, Tp = B * T, L.cpad(T)
@@ -1056,9 +1059,9 @@ def test_fused_attention_matches_unfused_and_torch(B, T, p):
         for fused in (False, True):
             A.FUSED_ATTENTION = fused
             ctx, P = A._attention_fwd(qkv, B, T, Tp, scale, True, drop)
-            dqkv = A._attention_bwd(dctx, qkv, P, B, T, Tp, scale, drop)
+            dqkv = A._attention_bwd(dctx, qkv, ctx, P, B, T, Tp, scale, drop)
             torch.cuda.synchronize()
-            assert (P is None) == fused
+            assert (P.dtype == torch.float32 and P.shape == (B * 12, T)) == fused   # fused: the log-sum-exp rows
             outs.append((ctx.float().cpu(), dqkv.float().cpu()))
     finally:
         A.FUSED_ATTENTION = True
