@@ -247,7 +247,19 @@ def _prep_qkv(att, need_dgrad, batch):
 
 
 def _prep_encoder_weights(enc, save):
-    """Every Linear operand of the encoder (16-bit [N][K] and, for the backward pass, its transpose) in ONE launch."""
+    """Every Linear operand of the encoder (16-bit [N][K] and, for the backward pass, its transpose) in ONE launch;
+    kept until a master changes (layers.cached_operands: gradient accumulation, validation, forward-only loops)."""
+    fp, tr = enc.feature_projection, enc.transformer
+    params = [fp.projection.weight, enc.readout.weight]
+    for layer in tr.layers:
+        att, ff = layer.attention, layer.feed_forward
+        for lin in (att.q_proj, att.k_proj, att.v_proj):
+            params += [lin.weight, lin.bias]
+        params += [att.out_proj.weight, ff.intermediate_dense.weight, ff.output_dense.weight]
+    return L.cached_operands(("wav2vec2-encoder", bool(save)), params, lambda: _build_encoder_weights(enc, save))
+
+
+def _build_encoder_weights(enc, save):
     fp, tr = enc.feature_projection, enc.transformer
     batch = L.CastBatch()
     w = {"proj": batch.linear(fp.projection.weight, save), "readout": batch.linear(enc.readout.weight, save)}

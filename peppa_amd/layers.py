@@ -101,8 +101,49 @@ class ConvGeom:
                              self.p, self.cg_out, self.out_cstride)
 
 
+# ---- operand cache ------------------------------------------------------------------------------------------------
+# The 16-bit operand layouts of a weight only change when the weight does.  With gradient accumulation (the reference
+# trains with accumulate_grad_batches: 8, hparams_base.yaml:42), in validation and in any forward-only loop the same
+# masters are re-laid for every micro-batch (~1.4 ms of small launches per pass): keep them until the masters move.
+# A master moves (i) through torch (`load_state_dict`, `copy_`, ...: its `_version` changes) or (ii) through
+# pp_bertadam_step, which writes through raw pointers: BertAdam.step() bumps WEIGHT_EPOCH.
+# Off by default: a caller that edits `p.data` in place changes a master without either signal.  peppa_amd.trainer.Trainer
+# owns the loop (weights move only in optimizer.step() and checkpoint loads) and switches it on.
+WEIGHT_EPOCH = 0
+_OPERANDS = {}
+_OPERANDS_EPOCH = [0]
+CACHE_OPERANDS = False
+
+
+def weights_changed():
+    """Called by whatever rewrites parameters behind torch's back (BertAdam.step)."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def cached_operands(key, params, build):
+    """build() -> operands of `params` (weights), memoised until one of them changes; key names the layout."""
+    if not CACHE_OPERANDS:
+        return build()
+    if _OPERANDS_EPOCH[0] != WEIGHT_EPOCH:
+        _OPERANDS.clear()
+        _OPERANDS_EPOCH[0] = WEIGHT_EPOCH
+    full = (key, H.precision()) + tuple((p.data_ptr(), p._version) for p in params)
+    hit = _OPERANDS.get(full)
+    if hit is None:
+        if len(_OPERANDS) > 4096:
+            _OPERANDS.clear()
+        hit = _OPERANDS[full] = build()
+    return hit
+
+
 def prep_conv_weights(w, geom, need_dgrad=True):
     """fp32 master [Co][Ci/groups][taps...] -> 16-bit operands (forward, dgrad)."""
+    key = ("conv", geom.Co, geom.Cig, geom.taps, geom.cg_in, geom.cg_out, geom.groups, geom.Ci, bool(need_dgrad))
+    return cached_operands(key, (w,), lambda: _prep_conv_weights(w, geom, need_dgrad))
+
+
+def _prep_conv_weights(w, geom, need_dgrad=True):
     Co, Cig, taps = geom.Co, geom.Cig, geom.taps
     wf = empty((Co, taps, geom.cg_in), act16(), w)
     H.prep_conv_weight(w, wf, Co, Cig, taps, Co, geom.cg_in)

@@ -138,4 +138,6 @@ class BertAdam(Optimizer):
                                 group['weight_decay'], group['max_grad_norm'], lr_t=lr_t)
                 for p in ps:
                     self.state[p]['step'] += 1
+        from . import layers as L
+        L.weights_changed()     # the masters moved through raw pointers: cached 16-bit operand layouts are stale
         return loss

@@ -77,6 +77,15 @@ class Trainer:
         return self.callback_metrics
 
     def fit(self, net, data):
+        from . import layers as L
+        prev_cache, L.CACHE_OPERANDS = L.CACHE_OPERANDS, True    # 16-bit weight operands live until optimizer.step()
+        try:
+            return self._fit(net, data)
+        finally:
+            L.CACHE_OPERANDS = prev_cache
+            L.weights_changed()
+
+    def _fit(self, net, data):
         optim = self.optimizer = net.configure_optimizers()
         if self.precision is not None and hasattr(net, "set_precision"):
             net.set_precision(self.precision)
