@@ -49,8 +49,10 @@ def main(args):
         from peppa_amd.video import ensure_streams
         ensure_streams(f"cuda:{local_rank}")            # the step's side streams before RCCL creates its own
         torch.distributed.init_process_group("nccl")    # lazy communicator: an eager one (device_id=) slows every kernel
+    batch_size = config['data']['train']['batch_size']
     data = SyntheticPigData(config['data'], frames=args.frames, size=args.size, samples=args.samples,
-                            steps_per_epoch=args.limit_train_batches or 100, device=f"cuda:{local_rank}")
+                            steps_per_epoch=args.limit_train_batches or 100, device=f"cuda:{local_rank}",
+                            val_batches=max(2, -(-100 // batch_size)))   # resampled_recall draws 100 clips (pig/metrics.py:55-56)
     net = pig.models.PeppaPig(config).to(f"cuda:{local_rank}")
     targs = dict(config['training']['trainer_args'])
     for key in ('accumulate_grad_batches', 'precision'):          # Trainer flags on the command line win (run.py:59-61)

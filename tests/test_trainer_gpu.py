@@ -144,3 +144,28 @@ def test_weight_operands_are_cached_between_optimizer_steps_and_never_stale():
     finally:
         L.CACHE_OPERANDS = False
         L.weights_changed()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,ok", [(["--random_init"], True), (["--random_init", "--precision", "fp16"], True), ([], False)])
+def test_run_py_cli(tmp_path, flags, ok):
+    """The reference's entry point (run.py:64-71) with the shipped yaml: `pretrained: true` cannot be honoured offline and
+    must stop the run with the reason (not silently train from random init); `--random_init` opts in; `--precision fp16`
+    trains on the half library with the loss scaler."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "run.py"), "--config_file", os.path.join(root, "hparams_base.yaml"),
+           "--limit_train_batches", "3", "--frames", "4", "--size", "32", "--samples", "4000", "--max_epochs", "1",
+           "--accumulate_grad_batches", "2", "--default_root_dir", str(tmp_path / "run")] + flags
+    env = dict(os.environ, PYTHONPATH=root)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    if ok:
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert os.path.exists(tmp_path / "run" / "hparams.yaml")
+        import yaml
+        saved = yaml.safe_load(open(tmp_path / "run" / "hparams.yaml"))
+        assert saved["video"]["pretrained"] is False and saved["audio"]["pretrained"] is False   # the EFFECTIVE setting
+        assert os.path.exists(tmp_path / "run" / "checkpoints" / "last.ckpt")
+    else:
+        assert res.returncode != 0 and "Kinetics" in res.stderr and "--random_init" in res.stderr
