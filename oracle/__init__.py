@@ -12,7 +12,10 @@ Pinning status (see DESIGN.md "Oracle"):
     in the build container (`oracle/make_golden.py` -> `tests/golden/ref_*.npz`).
   * wav2vec2-base: architecture pinned against an independent implementation
     (HF `transformers` Wav2Vec2Model built from a local config, eval mode).
-  * r2plus1d_18 / r3d_18 / mc3_18 / resnet18: the reference's own tests pin nothing
-    (it has none) and torchvision is not installed -> PARITY UNPINNED for the video
-    trunk beyond parameter counts, stage shapes and GMAC totals.
+  * resnet18 (static image encoder): architecture pinned against an independent
+    implementation (HF `transformers` ResNetModel from a local config, eval and train mode).
+  * r2plus1d_18 / r3d_18 / mc3_18: the reference's own tests pin nothing (it has
+    none), torchvision is not installed and no second implementation exists in the
+    container -> PARITY UNPINNED for the video trunk beyond parameter counts, mid-plane
+    widths, stage shapes and GMAC totals.
 """

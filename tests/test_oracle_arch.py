@@ -103,6 +103,60 @@ def test_wav2vec_matches_hf_implementation():
     assert torch.nn.functional.cosine_similarity(hid.flatten(), ref.flatten(), dim=0).item() > 0.999999
 
 
+def test_resnet18_matches_hf_implementation():
+    """The static encoder's trunk (pig/models.py:156-200: torchvision resnet18) against an independent implementation,
+    HF transformers' ResNetModel built from a local config (basic layers, depths 2-2-2-2, widths 64-512; nothing is fetched):
+    same parameter count as torchvision's resnet18 without `fc` (11 176 512) and the same activations in eval AND train mode
+    (batch statistics) once the restatement's weights are mapped onto it.  (No second implementation of the r2plus1d / r3d /
+    mc3 video trunks exists in this container: those stay pinned by parameter counts, mid-plane widths and stage shapes.)"""
+    pytest.importorskip("transformers")
+    from transformers import ResNetConfig, ResNetModel
+    torch.manual_seed(0)
+    ours = OV.ResNet18()
+    hf = ResNetModel(ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[64, 128, 256, 512], depths=[2, 2, 2, 2],
+                                  layer_type="basic", hidden_act="relu", downsample_in_first_stage=False))
+    assert _count(hf) == _count(ours) - _count(ours.fc) == 11176512
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():   # non-trivial BatchNorm parameters and running statistics
+        for m in ours.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.bias.shape, generator=g))
+    osd, new = ours.state_dict(), {}
+
+    def put(hf_prefix, conv, bn):
+        new[hf_prefix + ".convolution.weight"] = osd[conv + ".weight"]
+        for leaf in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            new[hf_prefix + ".normalization." + leaf] = osd[bn + "." + leaf]
+
+    put("embedder.embedder", "conv1", "bn1")
+    for si in range(4):
+        for bi in range(2):
+            o, h = f"layer{si + 1}.{bi}", f"encoder.stages.{si}.layers.{bi}"
+            put(h + ".layer.0", o + ".conv1", o + ".bn1")
+            put(h + ".layer.1", o + ".conv2", o + ".bn2")
+            if f"{o}.downsample.0.weight" in osd:
+                put(h + ".shortcut", o + ".downsample.0", o + ".downsample.1")
+    missing, unexpected = hf.load_state_dict(new, strict=True)
+    x = torch.rand(3, 3, 64, 64, generator=g)
+
+    def trunk(net, x):
+        y = net.maxpool(net.relu(net.bn1(net.conv1(x))))
+        return net.layer4(net.layer3(net.layer2(net.layer1(y))))
+
+    for mode in ("eval", "train"):
+        getattr(ours, mode)(); getattr(hf, mode)()
+        sd_o, sd_h = {k: v.clone() for k, v in ours.state_dict().items()}, {k: v.clone() for k, v in hf.state_dict().items()}
+        with torch.no_grad():
+            a = trunk(ours, x)
+            b = hf(x).last_hidden_state
+        ours.load_state_dict(sd_o); hf.load_state_dict(sd_h)    # (train mode moved the running statistics)
+        assert a.shape == b.shape == (3, 512, 2, 2)
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item()), (mode, (a - b).abs().max().item())
+
+
 def test_peppa_oracle_step_runs_c1_shape():
     cfg = {"margin": 0.2,
            "video": {"pretrained": False, "project": True, "version": "r2plus1d_18", "pooling": "attention"},
