@@ -215,6 +215,7 @@ def _conv_dgrad_strided(dy, geom, wd, residual):
     return dx
 
 
+MASKED_STRIDED_DGRAD = False   # A/B: stride-2 data gradients as ONE launch with masked taps instead of parity classes
 FUSE_BN_BWD_REDUCE = False   # consumer BatchNorm-backward sums in the data-gradient epilogue: built, tested, and OFF -- measured slower
 
 
@@ -224,7 +225,7 @@ def conv_dgrad(dy, geom, wd, *, residual=None, consumer=None):
     consumer = (y, z or None, BNSaved, relu) of the BatchNorm unit that receives dx as its dz: its backward sums
     (sum g, sum g * xhat) are then accumulated in the epilogue of the window kernels while the tile is on chip, and
     `consumer_partials(dx)` hands them to bn_bwd, which skips its own pass over dz."""
-    if geom.groups == 1 and max(geom.s) == 2:
+    if geom.groups == 1 and max(geom.s) == 2 and not MASKED_STRIDED_DGRAD:
         return _conv_dgrad_strided(dy, geom, wd, residual)
     dx = empty((geom.Min, geom.in_cstride), act16(), dy)
     if geom.groups == 1:

@@ -6,6 +6,8 @@ import torch
 from peppa_amd import hip as H, layers as L
 
 dev = "cuda"
+if os.environ.get("MASKED_STRIDED_DGRAD"):
+    L.MASKED_STRIDED_DGRAD = True
 B = int(os.environ.get("B", "64"))
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 case_filter = os.environ.get("CASE", "")
