@@ -27,8 +27,16 @@ int pp_opt_xcd_remap_wgrad = 1;
 // BatchNorm streaming passes (tools/bench_bn.py, layer-1 shapes): non-temporal STORES + 32 k workgroups instead of plain
 // stores + 4 k: apply 417 -> 370 us, backward apply 576 -> 485 us at 144 channels (4.4 / 4.8 -> 5.0 / 5.7 TB/s); non-temporal
 // loads on top bought nothing.  bit 0: non-temporal loads, bit 1: non-temporal stores.
+// Non-temporal stores of the output tile (window kernels: always; gather / ring kernels: outputs over 64 MB -- the
+// transformer's 11-MB activations are re-read from the caches by the next kernel).  tools/bench_gemm.py, layer-1 shapes:
+// forward 841 -> 828 us, data gradient 777 -> 766 us, temporal 393 -> 387 / 306 -> 300 us.
+int pp_opt_win_out_nt = 1;
 int pp_opt_bn_nt = 2;
 int pp_opt_bn_grid = 32768;
+static inline int out_nt_for(const pp_igemm_desc& d) {
+  return pp_opt_win_out_nt && !d.c_fp32 && (long long)d.M * d.ldc * 2 > (64LL << 20);
+}
+
 extern "C" int pp_set_option(const char* name, int value) {
   if (!name) return PP_ERR_INVALID;
   if (!strcmp(name, "xcd_remap_igemm")) { pp_opt_xcd_remap_igemm = value; return PP_OK; }
@@ -41,6 +49,7 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "persistent_igemm")) { pp_opt_persistent = value; return PP_OK; }
   if (!strcmp(name, "xcd_remap_wgrad")) { pp_opt_xcd_remap_wgrad = value; return PP_OK; }
   if (!strcmp(name, "bn_nt")) { pp_opt_bn_nt = value; return PP_OK; }
+  if (!strcmp(name, "win_out_nt")) { pp_opt_win_out_nt = value; return PP_OK; }
   if (!strcmp(name, "bn_grid")) { pp_opt_bn_grid = value > 0 ? value : 32768; return PP_OK; }
   pp_set_error("pp_set_option: unknown option %s", name);
   return PP_ERR_INVALID;
@@ -90,7 +99,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 //               counted vmcnt waits.  The swizzled LDS image is the same: the XOR moves to the source address.
 template <int WN, int MODE, bool FULL, int NW, bool RING>
 __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm_kernel(const pp_igemm_desc p, const int nblk_n,
-                                                                       const RowDiv rd, const int xcd_remap, const int ntiles) {
+                                                                       const RowDiv rd, const int xcd_remap, const int ntiles,
+                                                                       const int out_nt) {
   static_assert(!RING || (NW == 8 && WN <= 9), "ring variant: 8 waves, BN <= 144");
   constexpr int BM = 32 * NW;      // rows per workgroup: one 32-row slab per wave
   constexpr int NT = 64 * NW;      // threads
@@ -443,7 +453,12 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
             for (int q = 0; q < 8; ++q) x[q] += y[q];
             v = pack8(x);
           }
-          *(uint4*)(Cout + c_off + orow * p.ldc + col) = v;
+          if (out_nt) {      // large outputs are next read long after they left the caches: keep them out of the L2
+            u32x4 w = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w, (u32x4*)(Cout + c_off + orow * p.ldc + col));
+          } else {
+            *(uint4*)(Cout + c_off + orow * p.ldc + col) = v;
+          }
         }
       }
       if (RING) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -625,8 +640,8 @@ int launch_wn(const pp_igemm_desc& d, hipStream_t s) {
   dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(64 * NW);
   const RowDiv rd = make_rowdiv(d);
 #define PP_LAUNCH_IGEMM(MODE_)                                                                                       \
-  if (full) hipLaunchKernelGGL((igemm_kernel<WN, MODE_, true, NW, false>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles); \
-  else hipLaunchKernelGGL((igemm_kernel<WN, MODE_, false, NW, false>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles)
+  if (full) hipLaunchKernelGGL((igemm_kernel<WN, MODE_, true, NW, false>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles, out_nt_for(d)); \
+  else hipLaunchKernelGGL((igemm_kernel<WN, MODE_, false, NW, false>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles, out_nt_for(d))
   switch (d.g.mode) {
     case PP_DENSE: PP_LAUNCH_IGEMM(PP_DENSE); break;
     case PP_CONV_FWD: PP_LAUNCH_IGEMM(PP_CONV_FWD); break;
@@ -651,7 +666,7 @@ int launch_ring(const pp_igemm_desc& d, hipStream_t s) {
   const RowDiv rd = make_rowdiv(d);
   const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;
 #define PP_LAUNCH_RING(MODE_, FULL_) \
-  hipLaunchKernelGGL((igemm_kernel<WN, MODE_, FULL_, 8, true>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles)
+  hipLaunchKernelGGL((igemm_kernel<WN, MODE_, FULL_, 8, true>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles, out_nt_for(d))
   switch (d.g.mode) {   // (fused epilogues: dense, and conv-forward at 128 columns -- the other conv forms would spill)
     case PP_DENSE:
       if (full) PP_LAUNCH_RING(PP_DENSE, true);

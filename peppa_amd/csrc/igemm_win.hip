@@ -19,6 +19,7 @@
 extern int pp_opt_xcd_remap_igemm;
 extern int pp_opt_win_tall;
 extern int pp_opt_win_temporal;
+extern int pp_opt_win_out_nt;
 
 namespace {
 
@@ -95,7 +96,7 @@ struct WinArgs {
 // traffic, a launch) disappears; its read of y moves here.
 template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false>
 __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
-                                                          const int ntiles, const int xcd_remap) {
+                                                          const int ntiles, const int xcd_remap, const int out_nt) {
   constexpr int BM = 16 * MT * NW;
   // temporal tiles with narrow outputs: no halo rows at all and THREE window buffers -- the window of the phase after
   // next is in flight too, because a phase (3 short K-steps) is far shorter than an HBM round trip
@@ -364,7 +365,12 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
             for (int q = 0; q < 8; ++q) x[q] += y[q];
             v = pack8(x);
           }
-          *(uint4*)(p.C + (long long)m * p.ldc + col) = v;
+          if (out_nt) {      // non-temporal: the tile is next read by another kernel, long after it has left the L2
+            u32x4 w = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w, (u32x4*)(p.C + (long long)m * p.ldc + col));
+          } else {
+            *(uint4*)(p.C + (long long)m * p.ldc + col) = v;
+          }
           if (BNR) {   // the sums use the bf16 value just stored: exactly what pp_bn_bwd_reduce would read back as dz
             float d[8], yy[8], zz[8];
             unpack8(v, d);
@@ -615,14 +621,14 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   dim3 grid((unsigned)gx, 1, 1), block(NT);
   if constexpr (bnr_built<WN, CC, MT, TW>()) {
     if (d.bnr_partials) {
-      if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
-      else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+      if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+      else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
       PP_LAUNCH_CHECK();
       return PP_OK;
     }
   }
-  if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
-  else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm);
+  if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+  else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
   PP_LAUNCH_CHECK();
   return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
 }

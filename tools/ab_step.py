@@ -50,6 +50,9 @@ def set_switch(name, on):
         L.FUSE_BN_BWD_REDUCE = on
     elif name == "wgrad_side":
         PM.FORCE_WGRAD_SIDE = on
+    elif name == "out_nt":
+        from peppa_amd import hip as H
+        H.set_option("win_out_nt", 1 if on else 0)
     elif name == "bn_tuned":
         from peppa_amd import hip as H
         H.set_option("bn_nt", 2 if on else 0)
@@ -58,7 +61,7 @@ def set_switch(name, on):
         raise SystemExit(f"unknown switch {name}")
 
 
-defaults = {"fuse_bnr": False, "wgrad_side": False, "bn_tuned": True}
+defaults = {"fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
 for _ in range(3):
     step(0)
 for name in sys.argv[1:]:
