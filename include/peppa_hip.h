@@ -330,7 +330,9 @@ typedef struct pp_tensor_list {
 int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off,
                      int n_chunks, int chunk, float* norms /* [n_tensors] scratch */, float lr_scheduled,
                      float b1, float b2, float eps, float weight_decay, float max_grad_norm,
-                     const float* lr_per_tensor, pp_stream_t s);
+                     const float* lr_per_tensor,
+                     const float* skip_flag /* optional (device): != 0 -> the whole step is a no-op (fp16 overflow) */,
+                     pp_stream_t s);
 
 /* ---- dynamic loss scaling for the fp16 build (what Lightning's native AMP does around `BertAdam.step` under
  *      `precision: 16`, /root/reference/hparams_base.yaml:45; torch.cuda.amp.GradScaler semantics) -------------------- */

@@ -124,7 +124,7 @@ SIGNATURES = {
     "pp_cosine_matrix_bwd": [P, P, I, I, I, P, P, P, P, P],
     "pp_contrastive_bwd": [P, I, F, P, P, P, P],
     "pp_triplet_accuracy": [P, P, P, I, I, I, P, P],
-    "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P, P],
+    "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P, P, P],
 }
 _RESTYPE = {"pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z}
 _NO_STATUS = set(_RESTYPE) | {"pp_version", "pp_dtype"}

@@ -14,8 +14,10 @@ __device__ __forceinline__ bool aligned16(const void* a, const void* b, const vo
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const pp_tensor_list tl, const int* __restrict__ chunk_tensor,
-                                                    const long long* __restrict__ chunk_off, int chunk, float* norms) {
+                                                    const long long* __restrict__ chunk_off, int chunk, float* norms,
+                                                    const float* __restrict__ skip) {
   __shared__ float red[4];
+  if (skip && *skip != 0.f) return;     // an overflowed fp16 step: nothing is updated (uniform for the whole grid)
   const int t = chunk_tensor[blockIdx.x];
   const long long off = chunk_off[blockIdx.x];
   const long long n = tl.numel[t];
@@ -40,7 +42,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const pp_tensor_list tl, con
 __global__ __launch_bounds__(256) void bertadam_kernel(const pp_tensor_list tl, const int* __restrict__ chunk_tensor,
                                                        const long long* __restrict__ chunk_off, int chunk,
                                                        const float* __restrict__ norms, float lr, float b1, float b2, float eps,
-                                                       float wd, float max_norm, const float* __restrict__ lr_t) {
+                                                       float wd, float max_norm, const float* __restrict__ lr_t,
+                                                       const float* __restrict__ skip) {
+  if (skip && *skip != 0.f) return;
   const int t = chunk_tensor[blockIdx.x];
   if (lr_t) lr = lr_t[t];   // per-tensor scheduled learning rate (tensors whose step counts differ share one launch)
   const long long off = chunk_off[blockIdx.x];
@@ -163,15 +167,15 @@ extern "C" int pp_amp_update_scale(float* scale, int* growth_tracker, const floa
 
 extern "C" int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off, int n_chunks,
                                 int chunk, float* norms, float lr_scheduled, float b1, float b2, float eps, float weight_decay,
-                                float max_grad_norm, const float* lr_per_tensor, pp_stream_t s) {
+                                float max_grad_norm, const float* lr_per_tensor, const float* skip_flag, pp_stream_t s) {
   PP_CHECK_ARG(tl && tl->n_tensors > 0 && n_chunks > 0 && chunk > 0 && norms, "pp_bertadam_step: bad arguments");
   hipStream_t st = (hipStream_t)s;
   if (max_grad_norm > 0.f) {
     if (hipMemsetAsync(norms, 0, (size_t)tl->n_tensors * 4, st) != hipSuccess) { pp_set_error("pp_bertadam_step: memset"); return PP_ERR_HIP; }
-    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms, skip_flag);
   }
   hipLaunchKernelGGL(bertadam_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms, lr_scheduled,
-                     b1, b2, eps, weight_decay, max_grad_norm, lr_per_tensor);
+                     b1, b2, eps, weight_decay, max_grad_norm, lr_per_tensor, skip_flag);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

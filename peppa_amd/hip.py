@@ -486,9 +486,9 @@ def triplet_accuracy(a, p, n, discrete, out):
 
 
 # ---- optimizer -------------------------------------------------------------------------------------
-def bertadam_step(tl, chunk_tensor, chunk_off, n_chunks, chunk, norms, lr, b1, b2, eps, wd, max_norm, lr_t=None):
+def bertadam_step(tl, chunk_tensor, chunk_off, n_chunks, chunk, norms, lr, b1, b2, eps, wd, max_norm, lr_t=None, skip=None):
     call("pp_bertadam_step", C.byref(tl), _p(chunk_tensor, torch.int32), _p(chunk_off, torch.int64), n_chunks, chunk,
-         _p(norms, f32), lr, b1, b2, eps, wd, max_norm, _p(lr_t, f32), _s())
+         _p(norms, f32), lr, b1, b2, eps, wd, max_norm, _p(lr_t, f32), _p(skip, f32), _s())
 
 
 def grad_unscale_check(tl, chunk_tensor, chunk_off, n_chunks, chunk, scale, found_inf):

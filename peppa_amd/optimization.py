@@ -97,11 +97,16 @@ class BertAdam(Optimizer):
             self._chunk_cache[key] = (up(ct), up(co), int(counts.sum()), torch.empty(len(numels), dtype=f32, device=device))
         return self._chunk_cache[key]
 
-    def step(self, closure=None):
+    def step(self, closure=None, skip_flag=None):
+        """skip_flag (fp16 runs, peppa_amd.amp.GradScaler): a device float; non-zero = a gradient overflowed and the
+        launch leaves parameters and moments untouched.  The per-tensor step counters below are advanced here on the host
+        either way; `amp.GradScaler` takes the increment back one step later, when the flag has arrived, so the schedule
+        sees exactly the steps the reference's skipped `optimizer.step()` calls would have left (pig/optimization.py:160-170)."""
         loss = None
         if closure is not None:
             loss = closure()
         warned = False
+        self.last_stepped = []
         for group in self.param_groups:
             per_device = {}  # every tensor of the group with a gradient, per device: ONE fused launch pair
             for p in group['params']:
@@ -135,9 +140,10 @@ class BertAdam(Optimizer):
                 lr_t = torch.tensor(lrs, dtype=f32).pin_memory().to(device, non_blocking=True)
                 ct, co, n_chunks, norms = self._chunks([p.numel() for p in ps], device)
                 H.bertadam_step(tl, ct, co, n_chunks, _CHUNK, norms, float(lrs[0]), group['b1'], group['b2'], group['e'],
-                                group['weight_decay'], group['max_grad_norm'], lr_t=lr_t)
+                                group['weight_decay'], group['max_grad_norm'], lr_t=lr_t, skip=skip_flag)
                 for p in ps:
                     self.state[p]['step'] += 1
+                self.last_stepped += ps
         from . import layers as L
         L.weights_changed()     # the masters moved through raw pointers: cached 16-bit operand layouts are stale
         return loss

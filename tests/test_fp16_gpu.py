@@ -140,6 +140,40 @@ def test_grad_scaler_semantics():
     assert sc2.get_scale() == 512.0
 
 
+def test_grad_scaler_with_bertadam_skips_on_the_device_and_keeps_the_step_counters():
+    """With BertAdam the overflow decision never visits the host on the step path: the fused launch is a no-op when the
+    flag is set, and the per-tensor step counters (the warm-up schedule of pig/optimization.py:160-170) are corrected one
+    step later.  Trajectory against the oracle's BertAdam fed only the clean steps."""
+    import pig.optimization
+    from oracle import model as O
+    g = torch.Generator().manual_seed(4)
+    shapes = [(9,), (300, 70), (4, 5, 6)]
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g).to(DEV)) for s in shapes]
+    cpu = [p.detach().cpu().clone() for p in params]
+    kw = dict(lr=1e-2, warmup=0.3, t_total=10)
+    opt = pig.optimization.BertAdam(params, **kw)
+    sc = GradScaler(init_scale=256.0, growth_interval=1000)
+    st = {}
+    overflow_at = {2, 3}
+    for step in range(6):
+        grads = [torch.randn(*s, generator=g) * 0.3 for s in shapes]
+        for p, gr in zip(params, grads):
+            p.grad = (gr * sc.get_scale()).to(DEV)            # what backward of the scaled loss leaves
+        if step in overflow_at:
+            params[1].grad[5, 7] = float("inf")
+        before = [p.detach().clone() for p in params]
+        sc.step(opt)
+        sc.update()
+        if step in overflow_at:
+            assert all(torch.equal(p.detach(), b) for p, b in zip(params, before))
+        else:
+            O.bertadam_step(cpu, grads, st, **kw)
+            for p, pc in zip(params, cpu):
+                assert (p.detach().cpu() - pc).abs().max().item() <= 1e-6 + 1e-5 * pc.abs().max().item(), step
+    assert sc.skipped_steps == 2 and sc.get_scale() == 64.0
+    assert [opt.state[p]["step"] for p in params] == [4, 4, 4]
+
+
 def test_fp16_training_steps_with_loss_scaling():
     """A few optimizer steps of the whole model in fp16 under the built-in Trainer (precision="fp16"): BertAdam steps on
     unscaled gradients, nothing overflows into the weights, the loss stays finite and equals the bf16 run's within noise."""
