@@ -28,6 +28,7 @@ class GradScaler:
         self._enabled = enabled
         self._init_scale, self._growth, self._backoff, self._interval = float(init_scale), growth_factor, backoff_factor, growth_interval
         self._scale = self._tracker = self._found = None
+        self._init_tracker = 0
         self._unscaled = False
         self._tables = {}
         self._skipped = 0
@@ -57,7 +58,7 @@ class GradScaler:
     def _lazy_init(self, device):
         if self._scale is None:
             self._scale = torch.full((1,), self._init_scale, dtype=f32, device=device)
-            self._tracker = torch.zeros(1, dtype=torch.int32, device=device)
+            self._tracker = torch.full((1,), self._init_tracker, dtype=torch.int32, device=device)
             self._found = torch.zeros(1, dtype=f32, device=device)
 
     def scale(self, loss):
@@ -135,11 +136,12 @@ class GradScaler:
     def state_dict(self):
         self._reconcile()
         return {"scale": self.get_scale(), "growth_factor": self._growth, "backoff_factor": self._backoff,
-                "growth_interval": self._interval, "_growth_tracker": 0 if self._tracker is None else int(self._tracker.item())}
+                "growth_interval": self._interval, "_growth_tracker": self._init_tracker if self._tracker is None else int(self._tracker.item())}
 
     def load_state_dict(self, sd):
         self._init_scale = float(sd["scale"])
+        self._init_tracker = int(sd.get("_growth_tracker", 0))
         self._growth, self._backoff, self._interval = sd["growth_factor"], sd["backoff_factor"], sd["growth_interval"]
         if self._scale is not None:
             self._scale.fill_(self._init_scale)
-            self._tracker.fill_(int(sd.get("_growth_tracker", 0)))
+            self._tracker.fill_(self._init_tracker)

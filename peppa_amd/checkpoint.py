@@ -181,9 +181,11 @@ def optimizer_state(optimizer):
     return {"state": state, "param_groups": sd["param_groups"]}
 
 
-def save_checkpoint(path, net, optimizer=None, epoch=0, global_step=0, callback_state=None):
+def save_checkpoint(path, net, optimizer=None, epoch=0, global_step=0, callback_state=None, scaler=None):
     """Write a Lightning-1.4.9-shaped checkpoint.  `callback_state`: the ModelCheckpoint block
-    ({monitor, best_model_score, best_model_path, current_score, dirpath})."""
+    ({monitor, best_model_score, best_model_path, current_score, dirpath}).  `scaler`: the fp16 run's GradScaler; its state
+    goes where Lightning 1.4's native-AMP plugin puts it ("native_amp_scaling_state")."""
+    amp_state = None if scaler is None else scaler.state_dict()    # first: settles the step counters of a skipped step
     cp = {
         "epoch": int(epoch), "global_step": int(global_step), "pytorch-lightning_version": LIGHTNING_VERSION,
         "state_dict": {k: v.detach().cpu() for k, v in net.state_dict().items()},
@@ -193,6 +195,8 @@ def save_checkpoint(path, net, optimizer=None, epoch=0, global_step=0, callback_
         "hparams_name": "config",
         "hyper_parameters": _plain({k: v for k, v in net.config.items()}),
     }
+    if amp_state is not None:
+        cp["native_amp_scaling_state"] = amp_state
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     tmp = f"{path}.tmp"
     torch.save(cp, tmp)
@@ -300,7 +304,7 @@ class ModelCheckpoint:
             return True
         return score > self.best_model_score if self.mode == "max" else score < self.best_model_score
 
-    def on_validation_end(self, net, optimizer, epoch, global_step, metrics):
+    def on_validation_end(self, net, optimizer, epoch, global_step, metrics, scaler=None):
         """Called by the trainer after `validation_epoch_end`; returns the paths written."""
         if self.dirpath is None or self.monitor not in metrics:
             return []
@@ -310,10 +314,10 @@ class ModelCheckpoint:
         if self.save_top_k != 0 and self.better(score):
             path = os.path.join(self.dirpath, self.format_name(epoch, metrics))
             old, self.best_model_score, self.best_model_path = self.best_model_path, score, path
-            written.append(save_checkpoint(path, net, optimizer, epoch, global_step, self.state()))
+            written.append(save_checkpoint(path, net, optimizer, epoch, global_step, self.state(), scaler))
             if self.save_top_k == 1 and old and old != path and os.path.exists(old):
                 os.remove(old)
         if self.save_last:
             written.append(save_checkpoint(os.path.join(self.dirpath, "last.ckpt"), net, optimizer, epoch,
-                                           global_step, self.state()))
+                                           global_step, self.state(), scaler))
         return written

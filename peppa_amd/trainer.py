@@ -116,7 +116,7 @@ class Trainer:
                 rank0 = not is_dist() or torch.distributed.get_rank() == 0
                 for cb in self.callbacks:
                     if rank0:
-                        cb.on_validation_end(net, optim, epoch, self.global_step, metrics)
+                        cb.on_validation_end(net, optim, epoch, self.global_step, metrics, scaler=self.scaler)
         return net
 
     def _restore(self, net, optim, path):
@@ -128,6 +128,8 @@ class Trainer:
         if cp.get("optimizer_states"):
             optim.load_state_dict(cp["optimizer_states"][0])     # torch moves the state to each parameter's device
         self.global_step = int(cp.get("global_step", 0))
+        if self.scaler is not None and cp.get("native_amp_scaling_state"):
+            self.scaler.load_state_dict(cp["native_amp_scaling_state"])
         for state in callback_states(cp):
             for cb in self.callbacks:
                 if getattr(cb, "monitor", None) == state.get("monitor"):

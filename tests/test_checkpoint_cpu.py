@@ -237,3 +237,21 @@ def test_saving_leaves_the_live_optimizer_state_alone(tmp_path):
     cp = C.load_checkpoint(str(tmp_path / "a.ckpt"))
     assert torch.equal(cp["optimizer_states"][0]["state"][0]["momentum_buffer"],
                        opt.state[net.video_encoder.weight]["momentum_buffer"])
+
+
+def test_loss_scaler_state_rides_where_lightning_puts_it(tmp_path):
+    """An fp16 run's dynamic loss scale is saved under Lightning 1.4's "native_amp_scaling_state" and restored with its
+    growth tracker, also into a scaler that has not touched a device yet."""
+    from peppa_amd.amp import GradScaler
+    net = _tiny(0)
+    sc = GradScaler(init_scale=4096.0, growth_interval=2000)
+    sc.load_state_dict({"scale": 512.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,
+                        "_growth_tracker": 1234})
+    path = C.save_checkpoint(str(tmp_path / "s.ckpt"), net, scaler=sc)
+    cp = C.load_checkpoint(path)
+    assert cp["native_amp_scaling_state"] == {"scale": 512.0, "growth_factor": 2.0, "backoff_factor": 0.5,
+                                              "growth_interval": 2000, "_growth_tracker": 1234}
+    again = GradScaler()
+    again.load_state_dict(cp["native_amp_scaling_state"])
+    assert again.get_scale() == 512.0 and again._init_tracker == 1234
+    assert "native_amp_scaling_state" not in C.load_checkpoint(C.save_checkpoint(str(tmp_path / "n.ckpt"), net))
