@@ -21,8 +21,28 @@ extern int pp_opt_win_tall;
 extern int pp_opt_win_temporal;
 extern int pp_opt_win_out_nt;
 
+// Timing ablations for tools/probe/win_ablate.py (results are WRONG with any bit set; the shipped library has 0):
+// 1 weights only for a workgroup's first tile, 2 windows likewise, 4 no fragment reads / MFMAs, 8 no epilogue,
+// 16 fragment reads but no MFMAs, 32 epilogue without its global stores, 64 s_memtime stamps per wave and segment
+// (pp_debug_win_stamps copies them out: [workgroup][wave][wait, barrier, issue, multiply, tile turn, epilogue, total, -])
+#ifndef PP_WIN_ABLATE
+#define PP_WIN_ABLATE 0
+#endif
+
 namespace {
 
+constexpr int ABL = PP_WIN_ABLATE;
+#if PP_WIN_ABLATE & 64
+__device__ unsigned long long pp_win_stamp_buf[256 * 8 * 8];
+#define PP_STAMP(i)                                                      \
+  {                                                                      \
+    const unsigned long long t_ = stamp_now();                          \
+    tsum[i] += t_ - tlast;                                               \
+    tlast = t_;                                                          \
+  }
+#else
+#define PP_STAMP(i)
+#endif
 constexpr int BK = 64;
 constexpr int NW = 8, NT = 64 * NW;
 constexpr int HALO = 64;                      // rows kept on either side of the tile (>= W + 1)
@@ -63,6 +83,7 @@ struct WinGeom {
   // temporal (3,1,1) variant: a tile is ALL T frames of PB = BM / T consecutive positions of one clip
   FastDiv dBlk;  // position blocks per clip (H*W / PB)
   int nblk, T, HW, PB, pshift;
+  FastDiv dNb;   // column blocks per row block (tile -> (row block, column block))
 };
 
 struct WinArgs {
@@ -72,6 +93,7 @@ struct WinArgs {
   const h16raw* residual;
   float* colstats;
   int N, b_rows, ldb, ldc, ldr, ldstat;
+  unsigned a_bytes, b_bytes;   // sizes of A and Bt: the DMAs rely on the buffer resources' range check (rows outside A, absent weights)
   // BatchNorm-backward sums of the consumer of C, taken in the epilogue (pp_igemm_desc.bnr_*)
   const h16raw* bnr_y;
   const h16raw* bnr_z;
@@ -133,7 +155,6 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];   // one LDS object (see igemm.hip)
   unsigned char* const bring = smem + NWIN * WIN_BYTES;
   unsigned char* const zrow = smem + NWIN * WIN_BYTES + NBS * B_BYTES;    // 256 zero bytes
-  int* const lut = (int*)(zrow + 256);                                 // row offset of each tap
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,86 +170,111 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     const int t = (xcd_remap && cnt >= 8) ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3) : bid;
     return base + t;
   };
-  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)OOB, 0x00020000);
-  const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bt, (short)0, (int)OOB, 0x00020000);
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bt, (short)0, (int)p.b_bytes, 0x00020000);
   const int nchunk = g.cg / CC;
 
   if (tid < 64) ((unsigned*)zrow)[tid] = 0u;
-  if (tid < NTAP) lut[tid] = TW ? g.sign * (tid - 1) * g.PB : g.sign * ((tid / 3 - 1) * g.W + (tid % 3 - 1));
   __syncthreads();
   auto tw_row = [&](const int tile_m, const int lr) __attribute__((always_inline)) -> int {   // global row of tile row lr
     const int b = (int)fdiv((uint32_t)tile_m, g.dBlk);
     return (b * g.T + (lr >> g.pshift)) * g.HW + (tile_m - b * g.nblk) * g.PB + (lr & (g.PB - 1));
   };
 
-  // ---- window DMA: piece q = rwave + 4 k lands 1 KiB lane-linear; this lane's (window row, source byte column) ------
-  int w_row[NWP];
-  unsigned w_col[NWP];
+  // ---- window DMA: piece q = rwave + 4 k lands 1 KiB lane-linear.  Everything that depends on the lane is one byte
+  // offset per piece RELATIVE to the phase's first row, prepared once per workgroup; a phase adds one scalar.  Rows before
+  // the tensor wrap to offsets near 2^32 and rows past it lie beyond the resource's size: the hardware lands zeros for
+  // both, so there is no per-piece bounds arithmetic.  (48-channel rows: the 16 pad bytes of a 112-byte row fetch the next
+  // eight channels -- bytes of a line that is fetched anyway and that no fragment reads.) -----------------------------
+  // (spatial form, 64-channel rows: piece k + 1 lies 32 rows after piece k with the same swizzle, so one offset + a
+  // scalar stride do)
+  constexpr bool WLIN = CC == 64 && !TW;
+  constexpr int NVO = WLIN ? 1 : NWP;
+  unsigned w_voff[NVO];
 #pragma unroll
-  for (int k = 0; k < NWP; ++k) {
+  for (int k = 0; k < NVO; ++k) {
     const int q = rwave + NWW * k;
+    int row, cb;
     if (CC == 64) {
-      w_row[k] = q * 8 + (lane >> 3);
-      w_col[k] = (unsigned)(((lane & 7) ^ swz(w_row[k])) * 16);   // slot (lane & 7) holds chunk slot ^ swz(row)
+      row = q * 8 + (lane >> 3);
+      cb = ((lane & 7) ^ swz(row)) * 16;            // slot (lane & 7) holds chunk slot ^ swz(row)
     } else {
       const int o = q * 1024 + lane * 16;
-      w_row[k] = o / XS;
-      const int cb = o % XS;
-      w_col[k] = cb < CC * 2 ? (unsigned)cb : OOB;
+      row = o / XS;
+      cb = o - row * XS;
     }
+    const int lr = row - HALO_;
+    const int rel = TW ? (lr >> g.pshift) * g.HW + (lr & (g.PB - 1)) : lr;
+    w_voff[k] = (unsigned)(rel * g.cstride * 2 + cb);
   }
-  auto dma_window_piece = [&](const int k, unsigned char* wbuf, const int m0, const int chunk) __attribute__((always_inline)) {
+  const unsigned w_step = WLIN ? (unsigned)(8 * NWW * g.cstride * 2) : 0u;   // bytes between a wave's consecutive pieces
+  // temporal form with a halo (kept only as staging room for wide outputs): its pieces are never read, so never fetched
+  auto piece_live = [&](const int k) __attribute__((always_inline)) -> bool {
     const int q = rwave + NWW * k;
-    if (q < WPIECES) {
-      const int lr = w_row[k] - HALO_;
-      const int srow = TW ? tw_row(m0 / BM, lr) : m0 + lr;
-      const bool ok = (w_col[k] != OOB) & (TW ? (unsigned)lr < (unsigned)BM : (unsigned)srow < (unsigned)g.M);
-      lds_dma16(rsA, wbuf + q * 1024, ok ? (unsigned)(srow * g.cstride + chunk * CC) * 2u + w_col[k] : OOB);
-    }
+    if (TW && HALO_ > 0) return q * 1024 >= HALO_ * XS && (q + 1) * 1024 <= (HALO_ + BM) * XS;
+    return q < WPIECES;
   };
-  // ---- weight DMA (waves 0..3): rows 8 wave + (lane >> 3) + 32 i, slot lane & 7 holds K chunk (lane & 7) ^ swz(row) ------
+  bool abl_first = true;               // (ablations: still in the workgroup's first tile)
+  // byte offset of the first row of (tile, chunk)'s window
+  auto phase_base = [&](const int tile_, const int chunk_) __attribute__((always_inline)) -> unsigned {
+    const int mb_ = (int)fdiv((uint32_t)tile_, g.dNb);
+    int row0;
+    if (TW) {
+      const int b = (int)fdiv((uint32_t)mb_, g.dBlk);
+      row0 = b * g.T * g.HW + (mb_ - b * g.nblk) * g.PB;
+    } else {
+      row0 = mb_ * BM;
+    }
+    return (unsigned)(row0 * g.cstride + chunk_ * CC) * 2u;
+  };
+  auto dma_window_piece = [&](const int k, unsigned char* wbuf, const unsigned sbase) __attribute__((always_inline)) {
+    const int q = rwave + NWW * k;
+    if ((ABL & 2) && !abl_first) return;
+    if (piece_live(k)) lds_dma16(rsA, wbuf + q * 1024, WLIN ? sbase + (unsigned)k * w_step + w_voff[0] : sbase + w_voff[k]);
+  };
+  // pieces this (window) wave owns
+  int npieces = 0;
+#pragma unroll
+  for (int k = 0; k < NWP; ++k) npieces += piece_live(k) ? 1 : 0;
+  // ---- weight DMA (waves 0..3): rows 8 wave + (lane >> 3) + 32 i, slot lane & 7 holds K chunk (lane & 7) ^ swz(row).
+  // Source offset = row part (per tile) + K part of the K-step (per workgroup; flat (tap, channel) K inside a chunk, so a
+  // 48-channel chunk's K-step straddles taps and the part is per lane) + chunk (scalar).  0x80000000 marks "absent"
+  // (row past the matrix, K past the last tap): the sum stays beyond the resource's size and zeros land. ------------
+  constexpr unsigned ABSENT = 0x80000000u, ABSENT_K = 0x40000000u;   // (their sum does not wrap; Bt is < 2^30 bytes)
   const int brow0 = 8 * rwave + (lane >> 3);
   const int kqB = (lane & 7) ^ swz(brow0);
   const bool b_last = 8 * rwave + 8 * NWW * (NBI - 1) < BN;   // does this wave own a piece in the last weight pass
   const int nB = b_last ? NBI : NBI - 1;
-  unsigned bbase[NBI];
-  int tapB = 0, cB = 0, chunkB = 0, jB = 0;             // cursor of the next weight K-step to issue (inside the tile)
-  auto reset_b_cursor = [&]() __attribute__((always_inline)) {
-    const int kf = kqB * 8;
-    tapB = kf >= CC ? 1 : 0;
-    cB = kf - tapB * CC;
-    chunkB = 0;
-    jB = 0;
-  };
-  auto dma_weights = [&](unsigned char* slot) __attribute__((always_inline)) {   // issue the cursor's K-step, advance
-    const bool k_ok = tapB < NTAP;
-    const unsigned koff = (unsigned)(tapB * g.cg + chunkB * CC + cB) * 2u;
+  unsigned bvoff[NBI];
+  // (64-channel chunks: K-step j is tap j, channels kqB * 8 ..: the lane's part moves into the row offset)
+  constexpr int NKV = CC == 64 ? 1 : NKC;
+  unsigned kvoff[NKV];
+#pragma unroll
+  for (int j = 0; j < NKV; ++j) {
+    const int kf = j * BK + kqB * 8;
+    const int tap = kf / CC, c = kf - tap * CC;
+    kvoff[j] = tap < NTAP ? (unsigned)(tap * g.cg + c) * 2u : ABSENT_K;
+  }
+  auto dma_weights = [&](unsigned char* slot, const int chunk_, const int j) __attribute__((always_inline)) {
+    if ((ABL & 1) && !abl_first) return;
+    const unsigned koff = (CC == 64 ? (j < NTAP ? (unsigned)(j * g.cg) * 2u + kvoff[0] : ABSENT_K) : kvoff[j]) + (unsigned)(chunk_ * CC) * 2u;
     unsigned char* dst = slot + (8 * rwave) * 128;
 #pragma unroll
     for (int i = 0; i < NBI; ++i)
-      if (i < NBI - 1 || b_last) lds_dma16(rsB, dst + 8 * NWW * i * 128, (k_ok & (bbase[i] != OOB)) ? bbase[i] + koff : OOB);
-    cB += BK;
-    while (cB >= CC) { cB -= CC; ++tapB; }
-    if (++jB == NKC) {
-      jB = 0;
-      ++chunkB;
-      const int kf = kqB * 8;
-      tapB = kf >= CC ? 1 : 0;
-      cB = kf - tapB * CC;
-    }
+      if (i < NBI - 1 || b_last) lds_dma16(rsB, dst + 8 * NWW * i * 128, bvoff[i] + koff);
   };
 
   // ---- per-tile state -------------------------------------------------------------------------------------------
   int mb = 0, nb = 0;
   unsigned vmask[MT];    // bit t: tap t of fragment row (wave * 16 MT + mt * 16 + fr) lies inside the image
   auto setup_tile = [&](const int tile) __attribute__((always_inline)) {
-    nb = tile % nblk_n;
-    mb = tile / nblk_n;
+    mb = (int)fdiv((uint32_t)tile, g.dNb);
+    nb = tile - mb * nblk_n;
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
       const int brow = brow0 + 8 * NWW * i;
       const int n = nb * BN + brow;
-      bbase[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : OOB;
+      bvoff[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : ABSENT;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -255,46 +301,77 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   };
 
   f32x4 acc[MT][WN];
-  // one 64-deep K-step of chunk-flat K: lane's two k-octets (ks * 4 + fq) have their own (tap, channel)
-  int tapA[2], cA[2];
-  auto reset_a_cursor = [&]() __attribute__((always_inline)) {
+  // ---- fragment addressing, prepared once per workgroup.  Window row of fragment row (mt, fr) = rowA[mt] + tap offset;
+  // 64-channel chunks: a K-step is one tap (scalar offset), rows are XOR-swizzled; 48-channel chunks: the lane's k-octet
+  // of K-step j, half ks has its own (tap, channel) -- byte offset and tap bit per (j, ks) ----------------------------
+  int lutv[NTAP];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kf = (ks * 4 + fq) * 8;
-      tapA[ks] = kf >= CC ? 1 : 0;
-      cA[ks] = kf - tapA[ks] * CC;
-    }
-  };
-  auto compute = [&](const unsigned char* win, const unsigned char* bslot) __attribute__((always_inline)) {
+  for (int t = 0; t < NTAP; ++t) lutv[t] = TW ? g.sign * (t - 1) * g.PB : g.sign * ((t / 3 - 1) * g.W + (t % 3 - 1));
+  int rowA[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) rowA[mt] = wave * (16 * MT) + mt * 16 + fr + HALO_;
+  unsigned aoff[CC == 64 ? 1 : NKC][2], abit[CC == 64 ? 1 : NKC][2];
+  if (CC != 64) {
+#pragma unroll
+    for (int j = 0; j < NKC; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int k0 = j * BK + ks * 32;                        // the k-octets of this half start here
+        const int t0 = k0 / CC, r = k0 - t0 * CC + fq * 8;      // (fq * 8 <= 24 < CC: at most one tap further)
+        const bool hi = r >= CC;
+        const int tap = t0 + (hi ? 1 : 0), c = hi ? r - CC : r;
+        const int l0 = t0 < NTAP ? lutv[t0 < NTAP ? t0 : 0] : 0, l1 = t0 + 1 < NTAP ? lutv[t0 + 1 < NTAP ? t0 + 1 : 0] : 0;
+        aoff[j][ks] = (unsigned)((hi ? l1 : l0) * XS + c * 2);
+        abit[j][ks] = tap < NTAP ? 1u << tap : 0u;
+      }
+  }
+  const unsigned zaddr = (unsigned)(uintptr_t)(lds_ptr)(zrow + fr * 16);
+  const unsigned bfr0 = (unsigned)(fr * 128 + ((fq ^ swz(fr)) << 4));     // weight fragment (column fr, half 0) in a slot
+  // K-step j of a chunk (j is a compile-time constant after unrolling)
+  auto compute = [&](const int j, const unsigned char* win, const unsigned char* bslot) __attribute__((always_inline)) {
     // every fragment of the K-step is requested before the first MFMA: written as "load one weight fragment, use it"
     // hipcc keeps ONE fragment register and waits lgkmcnt(0) before every MFMA pair, i.e. one exposed LDS round trip
     // (~100 cycles) per 32 cycles of matrix work
     h16x8 af[2][MT], bfm[2][WN];
+    if (ABL & 4) return;
+    const unsigned wbase = (unsigned)(uintptr_t)(lds_ptr)win;
+    const unsigned bbase = (unsigned)(uintptr_t)(lds_ptr)bslot + bfr0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int tap = tapA[ks], c = cA[ks];
-      const int roff = lut[tap < NTAP ? tap : 0];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int wrow = wave * (16 * MT) + mt * 16 + fr + HALO_ + roff;
-        const int col = CC == 64 ? (((c >> 3) ^ swz(wrow)) << 4) : c * 2;
-        const bool ok = ((vmask[mt] >> tap) & 1u) != 0u;    // (tap >= NTAP, the K tail, has no bit set)
-        const unsigned char* a = ok ? win + wrow * XS + col : zrow + fr * 16;
-        af[ks][mt] = *(const h16x8*)a;
+        unsigned a;
+        bool ok;
+        if (CC == 64) {
+          const int wrow = rowA[mt] + lutv[j < NTAP ? j : 0];
+          a = wbase + (unsigned)(wrow * XS + (((ks * 4 + fq) ^ swz(wrow)) << 4));
+          ok = j < NTAP && ((vmask[mt] >> j) & 1u) != 0u;
+        } else {
+          a = wbase + (unsigned)(rowA[mt] * XS) + aoff[j][ks];
+          ok = (vmask[mt] & abit[j][ks]) != 0u;               // (the K tail has no bit)
+        }
+        af[ks][mt] = *(const h16x8*)(lds_ptr)(uintptr_t)(ok ? a : zaddr);
       }
-      const int fsw = ((ks * 4 + fq) ^ swz(fr)) << 4;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bfm[ks][j] = *(const h16x8*)(bslot + (j * 16 + fr) * 128 + fsw);
-      cA[ks] += BK;
-      while (cA[ks] >= CC) { cA[ks] -= CC; ++tapA[ks]; }
+      for (int jn = 0; jn < WN; ++jn) bfm[ks][jn] = *(const h16x8*)(lds_ptr)(uintptr_t)((bbase ^ (unsigned)(ks * 64)) + jn * 2048);
+    }
+    if (ABL & 16) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(af[ks][mt]));
+#pragma unroll
+        for (int jn = 0; jn < WN; ++jn) asm volatile("" ::"v"(bfm[ks][jn]));
+      }
+      return;
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+      for (int jn = 0; jn < WN; ++jn)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt][j] = PP_MFMA16(af[ks][mt], bfm[ks][j], acc[mt][j], 0, 0, 0);
+          acc[mt][jn] = PP_MFMA16(af[ks][mt], bfm[ks][jn], acc[mt][jn], 0, 0, 0);
   };
 
   // ---- epilogue (plain bf16 store, optional residual add, optional BatchNorm column statistics); igemm.hip's ------
@@ -365,7 +442,9 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
             for (int q = 0; q < 8; ++q) x[q] += y[q];
             v = pack8(x);
           }
-          if (out_nt) {      // non-temporal: the tile is next read by another kernel, long after it has left the L2
+          if (ABL & 32) {
+            asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+          } else if (out_nt) {      // non-temporal: the tile is next read by another kernel, long after it has left the L2
             u32x4 w = {v.x, v.y, v.z, v.w};
             __builtin_nontemporal_store(w, (u32x4*)(p.C + (long long)m * p.ldc + col));
           } else {
@@ -475,9 +554,11 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     }
   };
 
-  // ---- tile loop.  Phase = (tile, chunk); its window sits in buffer (phase counter & 1).  Iteration s of a tile:
-  //   wait for every DMA except the batch issued by iteration s - 1; barrier; issue the weights of step s + 2 and one
-  //   piece of the next phase's window; multiply step s.
+  // ---- tile loop.  Phase = (tile, chunk); its window sits in buffer (phase counter mod NWIN).  K-step j of a phase:
+  //   wait for every DMA except the batch issued by the previous K-step; barrier; issue the weights of the K-step
+  //   NBS - 1 ahead and a share of the window of the phase D ahead; multiply.  The K-steps of a chunk are unrolled: which
+  //   pieces, which tap, which fragment offsets are compile-time, and a K-step costs its MFMAs, its fragment reads and a
+  //   few dozen other instructions (it used to cost several hundred: cursors, divisions and a switch per piece).
   int it = 0;
   int tile = tile_index(0);
   if (tile < 0) return;
@@ -485,41 +566,57 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   int wsel = 0;                       // window buffer of the current phase
   int bsl = 0;                        // weight ring slot of the current K-step
   const int S = nchunk * NKC;         // K-steps per tile
-  reset_b_cursor();
-  // (tile iteration, chunk) of the phase `ahead` phases after (it_, chunk_); tile < 0: past the last phase
-  // k0 .. k0 + nk - 1: the pieces to issue now.  The temporal form issues a whole window at the start of a phase (its
-  // phases are three short K-steps); the spatial forms spread it over the K-steps of the phase.
   // (PMC note: the 512-row 48-channel-chunk variant fetches 1.55 GB for the 0.93-GB layer-1 data-gradient input, the
   // 256-row one 0.95 GB: consecutive chunks share 128-byte lines of the 288-byte rows, and 32 CUs x 2 x 70 KB of windows
   // in flight no longer fit one XCD's 4-MB L2.  It is still the faster of the two, 775 vs 945 us.)
-  auto issue_window = [&](const int it_, const int chunk_, const int ahead, const int cur_tile, unsigned char* buf,
-                          const int k0, const int nk) __attribute__((always_inline)) -> int {
+  // the phase `ahead` phases after (it_, chunk_): false past the last one, else its window's base offset
+  auto phase_ahead = [&](const int it_, const int chunk_, const int ahead, const int cur_tile, unsigned& sbase) __attribute__((always_inline)) -> bool {
     int pc = chunk_ + ahead, pit = it_;
     while (pc >= nchunk) { pc -= nchunk; ++pit; }
     const int ptile = pit == it_ ? cur_tile : tile_index(pit);
-    if (ptile < 0) return 0;
-    int n = 0;
-#pragma unroll
-    for (int k = 0; k < NWP; ++k)
-      if (k >= k0 && k < k0 + nk) {
-        dma_window_piece(k, buf, (ptile / nblk_n) * BM, pc);
-        n += (rwave + NWW * k < WPIECES) ? 1 : 0;
-      }
-    return n;
+    if (ptile < 0) return false;
+    sbase = phase_base(ptile, pc);
+    return true;
   };
+  constexpr int LA = RW ? 0 : NBS - 1;                          // weight K-steps in flight ahead of the multiply
   constexpr int PPK = TW ? NWP : (NWP + NKC - 1) / NKC;       // window pieces per window wave and K-step
   int last_win = 0;                   // window pieces this (window) wave issued at the previous phase start
   if (win_wave) {
 #pragma unroll
-    for (int a = 0; a < D; ++a) last_win = issue_window(0, 0, a, tile, smem + a * WIN_BYTES, 0, NWP);
+    for (int a = 0; a < D; ++a) {
+      unsigned sb = 0;
+      last_win = 0;
+      if (phase_ahead(0, 0, a, tile, sb)) {
+#pragma unroll
+        for (int k = 0; k < NWP; ++k) dma_window_piece(k, smem + a * WIN_BYTES, sb);
+        last_win = npieces;
+      }
+    }
   } else if (RW) {
-    for (int i = 0; i < S; ++i) dma_weights(bring + i * B_BYTES);   // (the launcher checked S <= NBS; same N block for every tile)
+    for (int c = 0; c < nchunk; ++c)      // (the launcher checked S <= NBS; same N block for every tile)
+#pragma unroll
+      for (int j = 0; j < NKC; ++j) dma_weights(bring + (c * NKC + j) * B_BYTES, c, j);
   } else {
-    dma_weights(bring);
-    if (NBS == 3 && S > 1) dma_weights(bring + B_BYTES);
+#pragma unroll
+    for (int a = 0; a < LA; ++a) dma_weights(bring + a * B_BYTES, 0, a);      // (NKC >= 6 > LA)
   }
   int last_batch = 0;                 // weight DMAs this (weight) wave issued in the previous iteration
+#if PP_WIN_ABLATE & 64
+  auto stamp_now = [&]() __attribute__((always_inline)) -> unsigned long long {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  };
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = stamp_now();
+  const unsigned long long tbegin = tlast;
+#endif
   bool drain = true;                  // first step of a tile: wait for everything (epilogue stores included)
+  auto slot_ahead = [&](const int sl) __attribute__((always_inline)) -> int {    // ring slot LA steps after slot sl
+    return NBS == 3 ? (sl >= 1 ? sl - 1 : 2) : (sl ^ 1);
+  };
   auto next_slot = [&](int sl) __attribute__((always_inline)) { return sl + 1 == NBS ? 0 : sl + 1; };
   while (true) {
 #pragma unroll
@@ -527,12 +624,13 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
 #pragma unroll
       for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int next_tile = tile_index(it + 1);
-    int s = 0;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-      reset_a_cursor();
       unsigned char* const win = smem + wsel * WIN_BYTES;
       unsigned char* const nwin = smem + (wsel + D >= NWIN ? wsel + D - NWIN : wsel + D) * WIN_BYTES;   // of the phase D ahead
-      for (int j = 0; j < NKC; ++j, ++s) {
+      unsigned nbase = 0;
+      const bool nvalid = win_wave && phase_ahead(it, chunk, D, tile, nbase);
+#pragma unroll
+      for (int j = 0; j < NKC; ++j) {
         // weight waves, three slots: everything but the batch of the previous iteration (the weights of step s + 1) must
         // have landed; two slots: that batch IS the weights of this step.  Window waves: this phase's window, issued at
         // the start of the previous phase, must have landed when the phase starts; nothing to wait for inside a phase.
@@ -544,22 +642,37 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
           wait_vmcnt_dyn((drain || NBS == 2 || RW) ? 0 : last_batch);
         }
         drain = false;
+        PP_STAMP(0)
         if (!RW || j == 0) __builtin_amdgcn_s_barrier();
+        PP_STAMP(1)
         if (win_wave) {
           if (TW) {
-            if (j == 0) last_win = issue_window(it, chunk, D, tile, nwin, 0, NWP);
-          } else {
-            issue_window(it, chunk, D, tile, nwin, j * PPK, PPK);
+            if (j == 0) {
+              last_win = 0;
+              if (nvalid) {
+#pragma unroll
+                for (int k = 0; k < NWP; ++k) dma_window_piece(k, nwin, nbase);
+                last_win = npieces;
+              }
+            }
+          } else if (nvalid) {
+#pragma unroll
+            for (int k = 0; k < NWP; ++k)
+              if (k >= j * PPK && k < (j + 1) * PPK) dma_window_piece(k, nwin, nbase);
           }
         } else if (!RW) {
-          int batch = 0;
-          if (s + (NBS - 1) < S) {
-            dma_weights(bring + (NBS == 3 ? (bsl >= 1 ? bsl - 1 : 2) : (bsl ^ 1)) * B_BYTES);
-            batch += nB;
+          // the K-step LA ahead: (chunk, j + LA), or the first ones of the next chunk
+          const int j2 = j + LA < NKC ? j + LA : j + LA - NKC;
+          const int c2 = j + LA < NKC ? chunk : chunk + 1;
+          last_batch = 0;
+          if (c2 < nchunk) {
+            dma_weights(bring + slot_ahead(bsl) * B_BYTES, c2, j2);
+            last_batch = nB;
           }
-          last_batch = batch;
         }
-        compute(win, bring + (RW ? s : bsl) * B_BYTES);
+        PP_STAMP(2)
+        compute(j, win, bring + (RW ? chunk * NKC + j : bsl) * B_BYTES);
+        PP_STAMP(3)
         bsl = next_slot(bsl);
       }
       wsel = wsel + 1 == NWIN ? 0 : wsel + 1;
@@ -572,20 +685,31 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     __builtin_amdgcn_s_barrier();                               // every wave is done reading it
     if (next_tile >= 0) {                                       // the next tile's first weight steps fly under the epilogue
       setup_tile(next_tile);
-      reset_b_cursor();
       // (two slots: the slot just consumed holds the statistics during the epilogue, so only the other one is refilled:
       // it is the slot of step 0 of the next tile because bsl already points past the consumed one)
       if (!win_wave && !RW) {
-        dma_weights(bring + bsl * B_BYTES);
-        if (NBS == 3 && S > 1) dma_weights(bring + next_slot(bsl) * B_BYTES);
+        int sl = bsl;
+#pragma unroll
+        for (int a = 0; a < LA; ++a) {
+          dma_weights(bring + sl * B_BYTES, 0, a);
+          sl = next_slot(sl);
+        }
       }
     }
-    epilogue(mb_done, nb_done, ebuf, sbuf);
+    PP_STAMP(4)
+    if (!(ABL & 8)) epilogue(mb_done, nb_done, ebuf, sbuf);
+    PP_STAMP(5)
+    abl_first = false;
     if (next_tile < 0) break;
     tile = next_tile;
     ++it;
     drain = true;
   }
+#if PP_WIN_ABLATE & 64
+  tsum[6] = stamp_now() - tbegin;
+  if (lane == 0 && bid < 256)
+    for (int i = 0; i < 8; ++i) pp_win_stamp_buf[(bid * 8 + wave) * 8 + i] = tsum[i];
+#endif
 }
 
 // (WN, CC, MT, TW) combinations the data gradients of r2plus1d_18 / r3d_18 / mc3_18 / resnet18 dispatch to get the BNR form
@@ -606,6 +730,8 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   while ((1 << g.pshift) < g.PB) ++g.pshift;
   g.nblk = g.HW / g.PB;
   g.dBlk = make_fastdiv((uint32_t)(g.nblk > 0 ? g.nblk : 1));
+  const int nblk_n = (d.N + BN - 1) / BN;
+  g.dNb = make_fastdiv((uint32_t)nblk_n);
   WinArgs a;
   a.A = (const h16raw*)d.A; a.Bt = (const h16raw*)d.Bt; a.C = (h16raw*)d.C; a.residual = (const h16raw*)d.residual;
   a.colstats = d.colstats;
@@ -613,7 +739,10 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   a.bnr_y = (const h16raw*)d.bnr_y; a.bnr_z = (const h16raw*)d.bnr_z;
   a.bnr_mean = d.bnr_mean; a.bnr_rstd = d.bnr_rstd; a.bnr_scale = d.bnr_scale; a.bnr_shift = d.bnr_shift;
   a.bnr_relu = d.bnr_relu; a.bnr_partials = d.bnr_partials;
-  const int nblk_n = (d.N + BN - 1) / BN;
+  a.a_bytes = (unsigned)((((long long)d.M - 1) * gg.cstride + gg.cg) * 2);
+  const long long b_bytes = (((long long)d.b_rows - 1) * d.ldb + d.K) * 2;
+  if (b_bytes <= 0 || b_bytes >= 0x40000000LL) { pp_set_error("pp_igemm: weight matrix too large for the window kernel"); return PP_ERR_INVALID; }
+  a.b_bytes = (unsigned)b_bytes;
   const long long nblk_m = ((long long)d.M + BM - 1) / BM;
   const long long ntiles = nblk_m * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
@@ -635,6 +764,12 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
 
 }  // namespace
 
+#if PP_WIN_ABLATE & 64
+extern "C" int pp_debug_win_stamps(void* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pp_win_stamp_buf), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // PP_OK if the window kernel took the problem, 1 if the shape is not one it handles (caller falls through), < 0 on error.
 // `d` has been validated by pp_igemm.
 int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
@@ -646,7 +781,7 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
                      !d.Cpre && !d.omap && g.kt == 3 && g.kh == 1 && g.kw == 1 && g.st == 1 && g.sh == 1 && g.sw == 1 &&
                      g.pt == 1 && g.ph == 0 && g.pw == 0 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && pb > 0 &&
                      (g.Gh * g.Gw) % pb == 0 && d.K == 3 * g.cg && d.M % 256 == 0 &&
-                     (long long)d.M * g.cstride < 0x7fffffffLL && (!d.residual || d.ldr % 8 == 0);
+                     (long long)d.M * g.cstride < 0x7f000000LL && (!d.residual || d.ldr % 8 == 0);
   if (tw_ok) {
     // resident weights: every K-step of a tile has its own ring slot (3 per channel chunk), one column block
     const int n16 = (d.N + 15) / 16;
@@ -660,7 +795,7 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
                         g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 &&
                         g.ph == 1 && g.pw == 1 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && g.Gw + 1 <= HALO &&
                         d.K == 9 * g.cg && (g.cg % 64 == 0 || g.cg % 48 == 0) &&
-                        (long long)d.M * g.cstride < 0x7fffffffLL && (!d.residual || d.ldr % 8 == 0);
+                        (long long)d.M * g.cstride < 0x7f000000LL && (!d.residual || d.ldr % 8 == 0);
   if (!shape_ok) return 1;
   const int n16 = (d.N + 15) / 16;
   // tile widths: 64 columns (narrow outputs) or 128 / 144 (whichever pads N less)
