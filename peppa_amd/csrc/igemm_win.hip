@@ -328,22 +328,34 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   const unsigned zaddr = (unsigned)(uintptr_t)(lds_ptr)(zrow + fr * 16);
   const unsigned bfr0 = (unsigned)(fr * 128 + ((fq ^ swz(fr)) << 4));     // weight fragment (column fr, half 0) in a slot
   // K-step j of a chunk (j is a compile-time constant after unrolling)
-  auto compute = [&](const int j, const unsigned char* win, const unsigned char* bslot) __attribute__((always_inline)) {
+  // `issue_dmas` runs between the fragment requests and the MFMAs: an LDS-DMA instruction takes 100+ cycles to issue, the
+  // fragments about as long to arrive
+  auto compute = [&](const int j, const unsigned char* win, const unsigned char* bslot, auto issue_dmas) __attribute__((always_inline)) {
     // every fragment of the K-step is requested before the first MFMA: written as "load one weight fragment, use it"
     // hipcc keeps ONE fragment register and waits lgkmcnt(0) before every MFMA pair, i.e. one exposed LDS round trip
     // (~100 cycles) per 32 cycles of matrix work
-    h16x8 af[2][MT], bfm[2][WN];
-    if (ABL & 4) return;
+    // Wide outputs (WN >= 8): the second half's weight fragments take the registers of the first half's, each requested
+    // right after the MFMAs that consumed its predecessor (18 x 4 registers of weights per half would not fit beside
+    // the 72 accumulators without spilling).
+    constexpr bool REUSE_B = WN >= 8;
+    h16x8 af[2][MT], bfm[REUSE_B ? 1 : 2][WN];
+    if (ABL & 4) {
+      issue_dmas();
+      return;
+    }
     const unsigned wbase = (unsigned)(uintptr_t)(lds_ptr)win;
     const unsigned bbase = (unsigned)(uintptr_t)(lds_ptr)bslot + bfr0;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    auto load_a = [&](const int ks) __attribute__((always_inline)) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         unsigned a;
         bool ok;
         if (CC == 64) {
-          const int wrow = rowA[mt] + lutv[j < NTAP ? j : 0];
+          // (the row is laundered through an empty asm: otherwise hipcc hoists the nine taps' addresses of every row tile
+          // out of the chunk loop and the 36 registers they occupy spill)
+          int r0 = rowA[mt];
+          asm volatile("" : "+v"(r0));
+          const int wrow = r0 + lutv[j < NTAP ? j : 0];
           a = wbase + (unsigned)(wrow * XS + (((ks * 4 + fq) ^ swz(wrow)) << 4));
           ok = j < NTAP && ((vmask[mt] >> j) & 1u) != 0u;
         } else {
@@ -352,26 +364,41 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         }
         af[ks][mt] = *(const h16x8*)(lds_ptr)(uintptr_t)(ok ? a : zaddr);
       }
+    };
+    auto load_b = [&](const int ks, const int jn) __attribute__((always_inline)) -> h16x8 {
+      return *(const h16x8*)(lds_ptr)(uintptr_t)((bbase ^ (unsigned)(ks * 64)) + jn * 2048);
+    };
+    load_a(0);
 #pragma unroll
-      for (int jn = 0; jn < WN; ++jn) bfm[ks][jn] = *(const h16x8*)(lds_ptr)(uintptr_t)((bbase ^ (unsigned)(ks * 64)) + jn * 2048);
+    for (int jn = 0; jn < WN; ++jn) bfm[0][jn] = load_b(0, jn);
+    load_a(1);
+    if (!REUSE_B) {
+#pragma unroll
+      for (int jn = 0; jn < WN; ++jn) bfm[REUSE_B ? 0 : 1][jn] = load_b(1, jn);
     }
+    issue_dmas();
     if (ABL & 16) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(af[ks][mt]));
 #pragma unroll
-        for (int jn = 0; jn < WN; ++jn) asm volatile("" ::"v"(bfm[ks][jn]));
+        for (int jn = 0; jn < WN; ++jn) asm volatile("" ::"v"(bfm[REUSE_B ? 0 : ks][jn]));
       }
       return;
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int jn = 0; jn < WN; ++jn)
+      for (int jn = 0; jn < WN; ++jn) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt][jn] = PP_MFMA16(af[ks][mt], bfm[ks][jn], acc[mt][jn], 0, 0, 0);
+          acc[mt][jn] = PP_MFMA16(af[ks][mt], bfm[REUSE_B ? 0 : ks][jn], acc[mt][jn], 0, 0, 0);
+        if (REUSE_B && ks == 0) {          // (pinned: left alone, hipcc sinks these reads to just before their MFMAs)
+          bfm[0][jn] = load_b(1, jn);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
   };
 
   // ---- epilogue (plain bf16 store, optional residual add, optional BatchNorm column statistics); igemm.hip's ------
@@ -645,33 +672,35 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         PP_STAMP(0)
         if (!RW || j == 0) __builtin_amdgcn_s_barrier();
         PP_STAMP(1)
-        if (win_wave) {
-          if (TW) {
-            if (j == 0) {
-              last_win = 0;
-              if (nvalid) {
+        auto issue_dmas = [&]() __attribute__((always_inline)) {
+          if (win_wave) {
+            if (TW) {
+              if (j == 0) {
+                last_win = 0;
+                if (nvalid) {
 #pragma unroll
-                for (int k = 0; k < NWP; ++k) dma_window_piece(k, nwin, nbase);
-                last_win = npieces;
+                  for (int k = 0; k < NWP; ++k) dma_window_piece(k, nwin, nbase);
+                  last_win = npieces;
+                }
               }
-            }
-          } else if (nvalid) {
+            } else if (nvalid) {
 #pragma unroll
-            for (int k = 0; k < NWP; ++k)
-              if (k >= j * PPK && k < (j + 1) * PPK) dma_window_piece(k, nwin, nbase);
+              for (int k = 0; k < NWP; ++k)
+                if (k >= j * PPK && k < (j + 1) * PPK) dma_window_piece(k, nwin, nbase);
+            }
+          } else if (!RW) {
+            // the K-step LA ahead: (chunk, j + LA), or the first ones of the next chunk
+            const int j2 = j + LA < NKC ? j + LA : j + LA - NKC;
+            const int c2 = j + LA < NKC ? chunk : chunk + 1;
+            last_batch = 0;
+            if (c2 < nchunk) {
+              dma_weights(bring + slot_ahead(bsl) * B_BYTES, c2, j2);
+              last_batch = nB;
+            }
           }
-        } else if (!RW) {
-          // the K-step LA ahead: (chunk, j + LA), or the first ones of the next chunk
-          const int j2 = j + LA < NKC ? j + LA : j + LA - NKC;
-          const int c2 = j + LA < NKC ? chunk : chunk + 1;
-          last_batch = 0;
-          if (c2 < nchunk) {
-            dma_weights(bring + slot_ahead(bsl) * B_BYTES, c2, j2);
-            last_batch = nB;
-          }
-        }
+        };
         PP_STAMP(2)
-        compute(j, win, bring + (RW ? chunk * NKC + j : bsl) * B_BYTES);
+        compute(j, win, bring + (RW ? chunk * NKC + j : bsl) * B_BYTES, issue_dmas);
         PP_STAMP(3)
         bsl = next_slot(bsl);
       }
