@@ -407,8 +407,24 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
       if (RING) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a fence would also drain the LDS-DMAs in flight)
       else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll(FULL ? 1 : (32 * WN + 63) / 64)   // (rolled for the fused epilogues: their unrolled form spills)
-      for (int it = 0; it < (32 * WN + 63) / 64; ++it) {
+      // ring, plain epilogue: every staged chunk of the pass is requested, then ONE wait (a wait per chunk exposed an LDS
+      // round trip each)
+      constexpr int NIT = (32 * WN + 63) / 64;
+      constexpr bool BATCH = RING && !FULL;
+      u32x4 vvs[BATCH ? NIT : 1];
+      if (BATCH) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int cid = lane + 64 * it;
+          const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(cid < 32 * WN ? stg + (cid / (2 * WN)) * STG_STRIDE + (cid % (2 * WN)) * 16 : stg);
+          asm volatile("ds_read_b128 %0, %1" : "=v"(vvs[it]) : "v"(a) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vvs[it]));
+      }
+#pragma unroll(FULL ? 1 : NIT)   // (rolled for the fused epilogues: their unrolled form spills)
+      for (int it = 0; it < NIT; ++it) {
         const int cid = lane + 64 * it;
         const int row = cid / (2 * WN);
         const int ch = cid % (2 * WN);
@@ -416,7 +432,10 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
         const int col = nb_e * BN + ch * 8;
         if (cid < 32 * WN && m < p.M && col < ncols_store) {
           uint4 v;
-          if (RING) {
+          if (BATCH) {
+            const u32x4 vv = vvs[BATCH ? it : 0];
+            v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+          } else if (RING) {
             // (hipcc drains vmcnt -- the next tile's LDS-DMAs and every earlier store -- before a plain LDS load here)
             const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(stg + row * STG_STRIDE + ch * 16);
             u32x4 vv;   // (a native vector type: the host pass must accept the constraint as well)

@@ -447,6 +447,21 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         for (int r = 0; r < 4; ++r) *(h16raw*)(stg_w + r * STG_STRIDE + j * 32) = f2h(acc[mt][j][r]);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      // all of the pass's staged chunks are requested, then ONE wait (one wait per chunk exposed an LDS round trip each).
+      // (inline asm: a plain LDS load here makes hipcc drain the DMAs in flight, see igemm.hip)
+      u32x4 vvs[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int cid = lane + 64 * it;
+        const int row = BNR ? b_rsub + RPI * it : cid / CPR;
+        const int ch = BNR ? b_ch : cid % CPR;
+        const bool live = BNR ? (b_rsub < RPI && row < 16) : cid < 32 * WN;
+        const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(live ? stg + row * STG_STRIDE + ch * 16 : stg);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(vvs[it]) : "v"(a) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vvs[it]));
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int cid = lane + 64 * it;
@@ -456,9 +471,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         const int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
         const int col = nb_e * BN + ch * 8;
         if (live && m < g.M && col < ncols_store) {
-          u32x4 vv;   // (inline asm: a plain LDS load here makes hipcc drain the DMAs in flight, see igemm.hip)
-          const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(stg + row * STG_STRIDE + ch * 16);
-          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vv) : "v"(a) : "memory");
+          const u32x4 vv = vvs[it];
           uint4 v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
           if (RES) {
             const uint4 rv = *(const uint4*)(p.residual + (long long)m * p.ldr + col);
@@ -640,7 +653,10 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   unsigned long long tlast = stamp_now();
   const unsigned long long tbegin = tlast;
 #endif
-  bool drain = true;                  // first step of a tile: wait for everything (epilogue stores included)
+  // (a tile's first waits also cover the previous epilogue's stores.  They are younger than the DMAs waited for, so a
+  // counted wait could leave them in flight: measured no faster.  Neither is leaving the last K-steps of a phase free of
+  // window pieces so that the youngest has longer to land.)
+  bool drain = true;                  // first step of a tile: wait for everything
   auto slot_ahead = [&](const int sl) __attribute__((always_inline)) -> int {    // ring slot LA steps after slot sl
     return NBS == 3 ? (sl >= 1 ? sl - 1 : 2) : (sl ^ 1);
   };

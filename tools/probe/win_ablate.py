@@ -12,14 +12,14 @@ def describe(bits):
     return " + ".join(v for k, v in NAMES.items() if bits & k) or "shipped"
 
 
-def build(bits):
+def build(bits, tag=""):
     from peppa_amd import build as B
     B.build_library(verbose=False)
     objdir = os.path.join(ROOT, "peppa_amd", "build")
     out_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pp_abl")
     os.makedirs(out_dir, exist_ok=True)
-    obj = os.path.join(out_dir, f"igemm_win_{bits}.o")
-    lib = os.path.join(out_dir, f"libpeppa_abl_{bits}.so")
+    obj = os.path.join(out_dir, f"igemm_win_{bits}{tag}.o")
+    lib = os.path.join(out_dir, f"libpeppa_abl_{bits}{tag}.so")
     extra = os.environ.get("ABL_FLAGS", "").split()
     subprocess.run([B.HIPCC] + B.FLAGS + extra + [f"-DPP_WIN_ABLATE={bits}", "-c", os.path.join(B.CSRC, "igemm_win.hip"), "-o", obj], check=True)
     others = [os.path.join(objdir, f) for f in sorted(os.listdir(objdir)) if f.endswith(".o") and f != "igemm_win.o"]
@@ -83,6 +83,13 @@ if __name__ == "__main__":
         measure(sys.argv[2])
     elif len(sys.argv) > 2 and sys.argv[1] == "--stamps-of":
         stamps(sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[1] == "--flags":       # A/B of -D switches: --flags "" "-DPP_WIN_SLACK=2" ...
+        for rep in range(2):
+            for i, fl in enumerate(sys.argv[2:]):
+                os.environ["ABL_FLAGS"] = fl
+                lib = build(0, f"_f{i}")
+                print(f"[{fl or 'default':30s}]", end=" ", flush=True)
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--measure", lib], check=True)
     elif len(sys.argv) > 1 and sys.argv[1] == "--stamps":
         for bits in [int(a) | 64 for a in sys.argv[2:]] or [64]:
             lib = build(bits)
