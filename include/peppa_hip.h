@@ -32,6 +32,7 @@ int pp_dtype(void);
  *   "xcd_remap_igemm", "xcd_remap_wgrad"  0/1   XCD-contiguous tile order
  *   "persistent_igemm"                    0/1   persistent workgroups with cross-tile prefetch (plain epilogues)
  *   "ring_igemm"   n   LDS-DMA ring GEMM once there are >= n 256-row tiles (0 = never; default 128)
+ *   "ring_wn"      w   dense ring tile width in 16-column units: 6, 8 or 9 (0 = chosen per problem, the default)
  *   "win_igemm"    n   window kernel for (1,3,3) stride-1 convs, forward / data gradient, once M >= n (default 1024)
  *   "win_temporal" 0/1 the same kernel in its temporal form for (3,1,1) stride-1 convs with 4 / 8 / 16 frames (default 1)
  *   "sw_wgrad"     n   sliding-window weight gradients ((1,3,3) and (3,1,1) stride-1 convs) once M >= n (default 4096;

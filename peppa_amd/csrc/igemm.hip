@@ -23,6 +23,7 @@ int pp_opt_win_igemm = 1024;   // window kernel for (1,3,3) stride-1 convs (forw
 int pp_opt_sw_wgrad = 4096;    // sliding-window weight gradient for (1,3,3) stride-1 convs once M >= this (0 = never)
 int pp_opt_ring_wgrad = 0;      // LDS-DMA ring weight gradient once the reduce dimension has this many rows (0 = never)
 int pp_opt_ring = 128; // LDS-DMA ring variant once there are this many 256-row tiles (0 = never)
+int pp_opt_ring_wn = 0;  // dense ring tile width in 16-column units (6, 8, 9; 0 = chosen per problem)
 int pp_opt_xcd_remap_wgrad = 1;
 // BatchNorm streaming passes (tools/bench_bn.py, layer-1 shapes): non-temporal STORES + 32 k workgroups instead of plain
 // stores + 4 k: apply 417 -> 370 us, backward apply 576 -> 485 us at 144 channels (4.4 / 4.8 -> 5.0 / 5.7 TB/s); non-temporal
@@ -46,6 +47,7 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "sw_wgrad")) { pp_opt_sw_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_wgrad")) { pp_opt_ring_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_igemm")) { pp_opt_ring = value; return PP_OK; }
+  if (!strcmp(name, "ring_wn")) { pp_opt_ring_wn = (value == 6 || value == 8 || value == 9) ? value : 0; return PP_OK; }
   if (!strcmp(name, "persistent_igemm")) { pp_opt_persistent = value; return PP_OK; }
   if (!strcmp(name, "xcd_remap_wgrad")) { pp_opt_xcd_remap_wgrad = value; return PP_OK; }
   if (!strcmp(name, "bn_nt")) { pp_opt_bn_nt = value; return PP_OK; }
@@ -696,12 +698,14 @@ int launch_ring(const pp_igemm_desc& d, hipStream_t s) {
         if (full) { PP_LAUNCH_RING(PP_CONV_FWD, true); break; }
       }
       if (full) { pp_set_error("pp_igemm: internal: fused conv epilogue on a ring tile without one"); return PP_ERR_INVALID; }
-      PP_LAUNCH_RING(PP_CONV_FWD, false);
-      break;
+      if constexpr (WN >= 8) { PP_LAUNCH_RING(PP_CONV_FWD, false); break; }
+      pp_set_error("pp_igemm: internal: conv gather on a dense-only ring tile");
+      return PP_ERR_INVALID;
     case PP_CONV_DGRAD:
       if (full) { pp_set_error("pp_igemm: internal: fused conv epilogue on a ring tile without one"); return PP_ERR_INVALID; }
-      PP_LAUNCH_RING(PP_CONV_DGRAD, false);
-      break;
+      if constexpr (WN >= 8) { PP_LAUNCH_RING(PP_CONV_DGRAD, false); break; }
+      pp_set_error("pp_igemm: internal: conv gather on a dense-only ring tile");
+      return PP_ERR_INVALID;
     default: pp_set_error("pp_igemm: bad gather mode %d", d.g.mode); return PP_ERR_INVALID;
   }
 #undef PP_LAUNCH_RING
@@ -786,11 +790,31 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
     // register-staged kernel, which measured faster there; so do GEMMs too small to give every CU a 256-row tile.
     // Fused epilogues (bias / activation / residual): dense at either width, conv-forward at 128 columns only.
     const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
-    const int best = c9 <= c8 ? 9 : 8;
+    int best = c9 <= c8 ? 9 : 8;
+    const long long mblk = ((long long)d.M + 255) / 256;
+    if (d.g.mode == PP_DENSE) {
+      // Dense: the width also decides how many rounds of 256 tiles the persistent workgroups walk.  M = 7296 x N = 768
+      // (the transformer's output projections) is 174 tiles of 128 columns -- two thirds of the CUs, one round -- but 232
+      // tiles of 96 columns, also one round, each a quarter less work.  Cost of a round ~ A rows + B rows streamed per
+      // K-step and the MFMAs, both linear in the width: (8 + width) fits the measured 96 / 128 / 144 column tiles.
+      long long best_cost = 0;
+      for (const int wn : {9, 8, 6}) {
+        const long long tiles = mblk * ((n16 + wn - 1) / wn);
+        const long long cost = ((tiles + 255) / 256) * (8 + wn);
+        if (best_cost == 0 || cost < best_cost) { best_cost = cost; best = wn; }
+      }
+      if (pp_opt_ring_wn) best = pp_opt_ring_wn;
+    }
     const bool epi_ok = !full || d.g.mode == PP_DENSE || (d.g.mode == PP_CONV_FWD && best == 8);
-    const long long tiles = (((long long)d.M + 255) / 256) * ((n16 + best - 1) / best);
+    const long long tiles = mblk * ((n16 + best - 1) / best);
     if (epi_ok && tiles >= pp_opt_ring) {
-      const int r = best == 9 ? launch_ring<9>(d, s) : launch_ring<8>(d, s);
+      int r;
+      if (best == 6) {
+        if (d.g.mode != PP_DENSE) { pp_set_error("pp_igemm: internal: 96-column ring tiles are dense only"); return PP_ERR_INVALID; }
+        r = launch_ring<6>(d, s);
+      } else {
+        r = best == 9 ? launch_ring<9>(d, s) : launch_ring<8>(d, s);
+      }
       return (r == PP_OK && d.bnr_partials) ? PP_BNR_SKIPPED : r;
     }
   }

@@ -28,6 +28,11 @@ extern int pp_opt_win_out_nt;
 #ifndef PP_WIN_ABLATE
 #define PP_WIN_ABLATE 0
 #endif
+// where in a K-step the window waves issue their LDS-DMA pieces: 0 before the fragment requests, 1 after them (where the
+// weight waves issue theirs), 2 between the two halves' MFMAs, 3 after the MFMAs
+#ifndef PP_WIN_WPOS
+#define PP_WIN_WPOS 0
+#endif
 
 namespace {
 
@@ -340,9 +345,10 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     constexpr bool REUSE_B = WN >= 8;
     h16x8 af[2][MT], bfm[REUSE_B ? 1 : 2][WN];
     if (ABL & 4) {
-      issue_dmas();
+      issue_dmas(-1);
       return;
     }
+    issue_dmas(0);
     const unsigned wbase = (unsigned)(uintptr_t)(lds_ptr)win;
     const unsigned bbase = (unsigned)(uintptr_t)(lds_ptr)bslot + bfr0;
     auto load_a = [&](const int ks) __attribute__((always_inline)) {
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
 #pragma unroll
       for (int jn = 0; jn < WN; ++jn) bfm[REUSE_B ? 0 : 1][jn] = load_b(1, jn);
     }
-    issue_dmas();
+    issue_dmas(1);
     if (ABL & 16) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -385,10 +391,12 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
 #pragma unroll
         for (int jn = 0; jn < WN; ++jn) asm volatile("" ::"v"(bfm[REUSE_B ? 0 : ks][jn]));
       }
+      issue_dmas(2);
+      issue_dmas(3);
       return;
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int jn = 0; jn < WN; ++jn) {
 #pragma unroll
@@ -399,6 +407,8 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      issue_dmas(2 + ks);
+    }
   };
 
   // ---- epilogue (plain bf16 store, optional residual add, optional BatchNorm column statistics); igemm.hip's ------
@@ -688,7 +698,8 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         PP_STAMP(0)
         if (!RW || j == 0) __builtin_amdgcn_s_barrier();
         PP_STAMP(1)
-        auto issue_dmas = [&]() __attribute__((always_inline)) {
+        auto issue_dmas = [&](const int pos) __attribute__((always_inline)) {
+          if (pos >= 0 && pos != (win_wave ? PP_WIN_WPOS : 1)) return;
           if (win_wave) {
             if (TW) {
               if (j == 0) {

@@ -720,6 +720,35 @@ def test_ring_igemm_matches_register_staged(case):
         assert torch.equal(a, b), f"{name}: ring differs from register-staged (max {(a.float() - b.float()).abs().max().item()})"
 
 
+@pytest.mark.parametrize("shape", [(7296, 768, 768), (1000, 200, 328), (2304, 96, 136)])
+def test_dense_ring_tile_widths_agree(shape):
+    """Dense ring GEMMs choose 96-, 128- or 144-column tiles by the number of rounds of 256 tiles (pp_set_option
+    "ring_wn" forces one): the width changes which workgroup computes an element, not the element -- bit-identical
+    outputs, plain and with the fused bias + GELU + residual epilogue; the transformer's M = 7296 x N = 768 shape
+    included."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N)
+    lf, _ = L.prep_linear((torch.randn(N, K, generator=g) * 0.05).to(DEV))
+    x = torch.randn(M, lf.shape[1], generator=g).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, L.cpad(N), generator=g).to(torch.bfloat16).to(DEV)
+    outs = []
+    try:
+        H.set_option("ring_igemm", 1)
+        for wn in (8, 6, 9, 0):
+            H.set_option("ring_wn", wn)
+            y = L.linear_fwd(x, M, lf, N)
+            yf = L.linear_fwd(x, M, lf, N, bias=bias, act=H.ACT_GELU, residual=res)
+            torch.cuda.synchronize()
+            outs.append((y[:, :N].clone(), yf[:, :N].clone()))
+    finally:
+        H.set_option("ring_wn", 0)
+        H.set_option("ring_igemm", H.RING_IGEMM_DEFAULT)
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+    close(outs[0][0], x.float()[:, :K] @ lf.float()[:, :K].t(), name="dense ring vs torch")
+
+
 @pytest.mark.parametrize("case", [
     # Ci, Co, k, s, p, B, T, H, W
     (64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), 2, 4, 28, 30),     # Kj = 576 = 3 x 192
