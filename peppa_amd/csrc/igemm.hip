@@ -23,6 +23,7 @@ int pp_opt_win_igemm = 1024;   // window kernel for (1,3,3) stride-1 convs (forw
 int pp_opt_sw_wgrad = 4096;    // sliding-window weight gradient for (1,3,3) stride-1 convs once M >= this (0 = never)
 int pp_opt_ring_wgrad = 0;      // LDS-DMA ring weight gradient once the reduce dimension has this many rows (0 = never)
 int pp_opt_ring = 128; // LDS-DMA ring variant once there are this many 256-row tiles (0 = never)
+int pp_opt_persist_cus = 256;   // workgroups of the persistent (one per CU) ring / window kernels
 int pp_opt_ring_wn = 0;  // dense ring tile width in 16-column units (6, 8, 9; 0 = chosen per problem)
 int pp_opt_xcd_remap_wgrad = 1;
 // BatchNorm streaming passes (tools/bench_bn.py, layer-1 shapes): non-temporal STORES + 32 k workgroups instead of plain
@@ -47,6 +48,7 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "sw_wgrad")) { pp_opt_sw_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_wgrad")) { pp_opt_ring_wgrad = value; return PP_OK; }
   if (!strcmp(name, "ring_igemm")) { pp_opt_ring = value; return PP_OK; }
+  if (!strcmp(name, "persist_cus")) { pp_opt_persist_cus = (value >= 8 && value <= 256) ? value : 256; return PP_OK; }
   if (!strcmp(name, "ring_wn")) { pp_opt_ring_wn = (value == 6 || value == 8 || value == 9) ? value : 0; return PP_OK; }
   if (!strcmp(name, "persistent_igemm")) { pp_opt_persistent = value; return PP_OK; }
   if (!strcmp(name, "xcd_remap_wgrad")) { pp_opt_xcd_remap_wgrad = value; return PP_OK; }
@@ -682,7 +684,7 @@ int launch_ring(const pp_igemm_desc& d, hipStream_t s) {
   const long long nblk_m = ((long long)d.M + BM - 1) / BM;
   const long long ntiles = nblk_m * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
-  const long long gx = ntiles < 256 ? ntiles : 256;
+  const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
   dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(512);
   const RowDiv rd = make_rowdiv(d);
   const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;

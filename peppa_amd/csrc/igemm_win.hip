@@ -20,6 +20,7 @@ extern int pp_opt_xcd_remap_igemm;
 extern int pp_opt_win_tall;
 extern int pp_opt_win_temporal;
 extern int pp_opt_win_out_nt;
+extern int pp_opt_persist_cus;
 
 // Timing ablations for tools/probe/win_ablate.py (results are WRONG with any bit set; the shipped library has 0):
 // 1 weights only for a workgroup's first tile, 2 windows likewise, 4 no fragment reads / MFMAs, 8 no epilogue,
@@ -802,7 +803,7 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   const long long nblk_m = ((long long)d.M + BM - 1) / BM;
   const long long ntiles = nblk_m * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
-  const long long gx = ntiles < 256 ? ntiles : 256;
+  const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
   if constexpr (bnr_built<WN, CC, MT, TW>()) {
     if (d.bnr_partials) {
