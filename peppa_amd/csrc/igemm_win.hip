@@ -617,9 +617,9 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   int wsel = 0;                       // window buffer of the current phase
   int bsl = 0;                        // weight ring slot of the current K-step
   const int S = nchunk * NKC;         // K-steps per tile
-  // (PMC note: the 512-row 48-channel-chunk variant fetches 1.55 GB for the 0.93-GB layer-1 data-gradient input, the
+  // (PMC note: the 512-row 48-channel-chunk variant fetches 1.43 GB for the 0.93-GB layer-1 data-gradient input, the
   // 256-row one 0.95 GB: consecutive chunks share 128-byte lines of the 288-byte rows, and 32 CUs x 2 x 70 KB of windows
-  // in flight no longer fit one XCD's 4-MB L2.  It is still the faster of the two, 775 vs 945 us.)
+  // in flight no longer fit one XCD's 4-MB L2.  It is still the faster of the two: profiles/r02_pmc_traffic.md.)
   // the phase `ahead` phases after (it_, chunk_): false past the last one, else its window's base offset
   auto phase_ahead = [&](const int it_, const int chunk_, const int ahead, const int cur_tile, unsigned& sbase) __attribute__((always_inline)) -> bool {
     int pc = chunk_ + ahead, pit = it_;
