@@ -37,7 +37,11 @@ int pp_dtype(void);
  *   "win_temporal" 0/1 the same kernel in its temporal form for (3,1,1) stride-1 convs with 4 / 8 / 16 frames (default 1)
  *   "sw_wgrad"     n   sliding-window weight gradients ((1,3,3) and (3,1,1) stride-1 convs) once M >= n (default 4096;
  *                      1 also takes shapes the (3,1,1) kernel would decline as not worth it)
- *   "ring_wgrad"   n   LDS-DMA ring variant of the generic weight gradient once M >= n (default 0 = never) */
+ *   "ring_wgrad"   n   LDS-DMA ring variant of the generic weight gradient once M >= n (default 0 = never)
+ *   "win_tall"     0/1/2  512-row window tiles for narrow outputs (1: with enough rows, the default; 2: always)
+ *   "win_out_nt"   0/1 non-temporal stores of the window kernels' output tiles (default 1)
+ *   "bn_nt" b, "bn_grid" n   BatchNorm streaming passes: non-temporal loads (bit 0) / stores (bit 1), workgroups per launch
+ *   "persist_cus"  n   workgroups of the persistent ring / window kernels (8..256, default 256 = one per CU) */
 int pp_set_option(const char* name, int value);
 const char* pp_last_error(void);
 
