@@ -100,9 +100,16 @@ typedef struct pp_igemm_desc {
   const void* bnr_y; const void* bnr_z;
   const float* bnr_mean; const float* bnr_rstd; const float* bnr_scale; const float* bnr_shift;
   int bnr_relu; float* bnr_partials;
+  /* optional (conv forward): A is the RAW output y of a BatchNorm unit and the kernel reads z = relu?(y * a_bn_scale +
+   * a_bn_shift) instead -- applied to each activation window once, in LDS, so the unit's activated tensor is never
+   * written or read (the convolution's zero padding applies to z).  fp32 [cg] each.  Only the temporal window kernel
+   * implements it: ask pp_igemm_abn_supported(d) first; pp_igemm fails with PP_ERR_INVALID for any other problem. */
+  const float* a_bn_scale; const float* a_bn_shift; int a_bn_relu;
 } pp_igemm_desc;
 #define PP_BNR_SKIPPED 2
 int pp_igemm(const pp_igemm_desc* d, pp_stream_t s);
+/* 1 if pp_igemm would run `d` (sizes, gather, epilogue; pointers are not looked at) with a_bn_scale / a_bn_shift, else 0 */
+int pp_igemm_abn_supported(const pp_igemm_desc* d);
 
 /* dW[Ni,Kj] += sum_m dY[m,Ni]^T * X_gather[m,Kj]  (weight gradients; fp32 atomics).
  * Replaces autograd's conv/linear weight-gradient for the same modules. dW must be zeroed. */
@@ -117,8 +124,12 @@ typedef struct pp_wgrad_desc {
   long long x_s, dy_s, dw_s;      /* per-batch offsets (elements) */
   float* dbias;                   /* optional: dbias[Ni] += column sums of dY (zeroed by the caller) */
   long long dbias_s;
+  /* optional: X is the RAW output y of a BatchNorm unit; the kernel uses relu?(y * x_bn_scale + x_bn_shift) (see
+   * pp_igemm_desc.a_bn_scale).  Only the temporal sliding-window kernel implements it: pp_wgrad_xbn_supported(d). */
+  const float* x_bn_scale; const float* x_bn_shift; int x_bn_relu;
 } pp_wgrad_desc;
 int pp_wgrad(const pp_wgrad_desc* d, pp_stream_t s);
+int pp_wgrad_xbn_supported(const pp_wgrad_desc* d);
 
 /* ---- weight preparation (fp32 master -> bf16 operand layouts) and gradient un-preparation */
 /* w [Co][Ci][taps] fp32 -> out [rows_out][taps][cg] bf16 (zero padded), optional tap flip.

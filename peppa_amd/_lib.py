@@ -36,7 +36,8 @@ class IGemmDesc(C.Structure):
         ("os_w", C.c_int), ("oo_t", C.c_int), ("oo_h", C.c_int), ("oo_w", C.c_int),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint),
         ("bnr_y", C.c_void_p), ("bnr_z", C.c_void_p), ("bnr_mean", C.c_void_p), ("bnr_rstd", C.c_void_p),
-        ("bnr_scale", C.c_void_p), ("bnr_shift", C.c_void_p), ("bnr_relu", C.c_int), ("bnr_partials", C.c_void_p)]
+        ("bnr_scale", C.c_void_p), ("bnr_shift", C.c_void_p), ("bnr_relu", C.c_int), ("bnr_partials", C.c_void_p),
+        ("a_bn_scale", C.c_void_p), ("a_bn_shift", C.c_void_p), ("a_bn_relu", C.c_int)]
 
 
 class WGradDesc(C.Structure):
@@ -45,7 +46,8 @@ class WGradDesc(C.Structure):
         ("X", C.c_void_p), ("dY", C.c_void_p), ("ldy", C.c_int), ("dW", C.c_void_p), ("ldw", C.c_int),
         ("msplit", C.c_int), ("nbatch", C.c_int),
         ("x_s", C.c_longlong), ("dy_s", C.c_longlong), ("dw_s", C.c_longlong),
-        ("dbias", C.c_void_p), ("dbias_s", C.c_longlong)]
+        ("dbias", C.c_void_p), ("dbias_s", C.c_longlong),
+        ("x_bn_scale", C.c_void_p), ("x_bn_shift", C.c_void_p), ("x_bn_relu", C.c_int)]
 
 
 class TensorList(C.Structure):
@@ -65,6 +67,8 @@ SIGNATURES = {
     "pp_set_option": [C.c_char_p, I],
     "pp_igemm": [C.POINTER(IGemmDesc), P],
     "pp_wgrad": [C.POINTER(WGradDesc), P],
+    "pp_igemm_abn_supported": [C.POINTER(IGemmDesc)],
+    "pp_wgrad_xbn_supported": [C.POINTER(WGradDesc)],
     "pp_prep_conv_weight": [P, I, I, I, P, I, I, I, I, F, P],
     "pp_select_taps": [P, I, I, I, C.POINTER(I), I, P, P],
     "pp_unprep_conv_grad": [P, I, I, I, I, P, P],

@@ -60,6 +60,7 @@ extern "C" int pp_set_option(const char* name, int value) {
 }
 
 int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s);
+int pp_igemm_abn_ok(const pp_igemm_desc& d);
 
 namespace {
 
@@ -737,6 +738,15 @@ int pp_validate_gather(const pp_gather& g, int K, const char* who) {
   return PP_OK;
 }
 
+extern "C" int pp_igemm_abn_supported(const pp_igemm_desc* dp) {
+  if (!dp) return 0;
+  pp_igemm_desc d = *dp;
+  if (d.b_rows <= 0) d.b_rows = d.N;
+  if (d.nbatch <= 0) d.nbatch = 1;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || pp_validate_gather(d.g, d.K, "pp_igemm_abn_supported") != PP_OK) return 0;
+  return pp_igemm_abn_ok(d);
+}
+
 extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   PP_CHECK_ARG(dp != nullptr, "pp_igemm: null descriptor");
   pp_igemm_desc d = *dp;
@@ -780,6 +790,10 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
     PP_CHECK_ARG((long long)d.M * d.g.lda < 0x7fffffffLL, "pp_igemm: dense operand >= 2^31 elements");
   }
   PP_CHECK_ARG((long long)d.b_rows * d.ldb < 0x7ffffff0LL, "pp_igemm: Bt has >= 2^31 elements");
+  if (d.a_bn_scale || d.a_bn_shift)
+    PP_CHECK_ARG(d.a_bn_scale && d.a_bn_shift && pp_igemm_abn_ok(d),
+                 "pp_igemm: a_bn_scale / a_bn_shift (BatchNorm apply of A's producer) is not available for this problem: "
+                 "ask pp_igemm_abn_supported first");
   hipStream_t s = (hipStream_t)stream;
   if (pp_opt_win_igemm && (long long)d.M >= pp_opt_win_igemm) {   // (1,3,3) stride-1 convs: A window in LDS
     const int rc_win = pp_igemm_win_try(d, s);

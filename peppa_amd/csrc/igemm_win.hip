@@ -21,6 +21,7 @@ extern int pp_opt_win_tall;
 extern int pp_opt_win_temporal;
 extern int pp_opt_win_out_nt;
 extern int pp_opt_persist_cus;
+extern int pp_opt_win_igemm;
 
 // Timing ablations for tools/probe/win_ablate.py (results are WRONG with any bit set; the shipped library has 0):
 // 1 weights only for a workgroup's first tile, 2 windows likewise, 4 no fragment reads / MFMAs, 8 no epilogue,
@@ -106,6 +107,10 @@ struct WinArgs {
   const float *bnr_mean, *bnr_rstd, *bnr_scale, *bnr_shift;
   int bnr_relu;
   float* bnr_partials;
+  // BatchNorm apply (+ ReLU) of the PRODUCER of A, done on each window in LDS (BNA): A is then the raw conv output y and
+  // the activated tensor z = relu(y * scale + shift) is never materialised
+  const float *bna_scale, *bna_shift;
+  int bna_relu;
 };
 
 // MT = 16-row tiles per wave (2: 256-row workgroup tile; 4: 512 rows -- narrow outputs, where a weight fragment would
@@ -122,7 +127,7 @@ struct WinArgs {
 // BNR = the epilogue also accumulates the BatchNorm-backward sums (sum g, sum g * xhat) of the layer that consumes this
 // output as its dz: the tile is in registers / LDS anyway, so bn_bwd_reduce's pass over dz (2 B per element of HBM
 // traffic, a launch) disappears; its read of y moves here.
-template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false>
+template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false>
 __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap, const int out_nt) {
   constexpr int BM = 16 * MT * NW;
@@ -156,8 +161,10 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   constexpr int STAT_BYTES = NW * BN * 2 * 4;
   static_assert(STG_BYTES <= WIN_BYTES && STAT_BYTES <= B_BYTES, "the epilogue stages in a window buffer / weight slot");
   static_assert(!RW || WN > 4 || STG_BYTES + STAT_BYTES <= WIN_BYTES, "resident weights: the statistics stage behind the output");
-  constexpr int SMEM = NWIN * WIN_BYTES + NBS * B_BYTES + 256 + 64;
+  constexpr int BNA_CH = 160;                                 // channels of the BatchNorm parameter table (BNA)
+  constexpr int SMEM = NWIN * WIN_BYTES + NBS * B_BYTES + 256 + 64 + (BNA ? 2 * BNA_CH * 4 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
+  static_assert(!BNA || (TW && CC == 48), "BNA: temporal form, 48-channel chunks");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];   // one LDS object (see igemm.hip)
   unsigned char* const bring = smem + NWIN * WIN_BYTES;
   unsigned char* const zrow = smem + NWIN * WIN_BYTES + NBS * B_BYTES;    // 256 zero bytes
@@ -181,6 +188,13 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   const int nchunk = g.cg / CC;
 
   if (tid < 64) ((unsigned*)zrow)[tid] = 0u;
+  float* const bna_tab = (float*)(zrow + 256 + 64);          // [scale BNA_CH][shift BNA_CH]
+  if (BNA) {
+    for (int i = tid; i < BNA_CH; i += NT) {
+      bna_tab[i] = i < g.cg ? p.bna_scale[i] : 0.f;
+      bna_tab[BNA_CH + i] = i < g.cg ? p.bna_shift[i] : 0.f;
+    }
+  }
   __syncthreads();
   auto tw_row = [&](const int tile_m, const int lr) __attribute__((always_inline)) -> int {   // global row of tile row lr
     const int b = (int)fdiv((uint32_t)tile_m, g.dBlk);
@@ -698,6 +712,44 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         drain = false;
         PP_STAMP(0)
         if (!RW || j == 0) __builtin_amdgcn_s_barrier();
+        if (BNA && j == 0) {
+          // z = relu(y * scale + shift) on the window that has just landed: 256 rows x six 8-channel octets, three per
+          // thread; then every wave sees the activated rows (the masked taps' zero row is the conv's zero padding of z)
+          constexpr int NOCT = BM * (CC / 8);
+#pragma unroll
+          for (int k = 0; k < (NOCT + NT - 1) / NT; ++k) {
+            const int idx = tid + NT * k;
+            if (idx < NOCT) {
+              const int row = idx / (CC / 8), c8 = idx % (CC / 8);
+              // (inline asm throughout: plain LDS accesses here make hipcc wait for every LDS-DMA in flight -- the windows
+              // of the next two phases -- before them and again in the K-steps)
+              const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(win + row * XS + c8 * 16);
+              const unsigned t = (unsigned)(uintptr_t)(lds_ptr)(bna_tab + chunk * CC + c8 * 8);
+              u32x4 vv, s0, s1, h0, h1;
+              asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
+                           "ds_read_b128 %3, %6 offset:%7\n\tds_read_b128 %4, %6 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                           : "=&v"(vv), "=&v"(s0), "=&v"(s1), "=&v"(h0), "=&v"(h1)
+                           : "v"(a), "v"(t), "n"(BNA_CH * 4), "n"(BNA_CH * 4 + 16)
+                           : "memory");
+              float x[8];
+              unpack8(make_uint4(vv[0], vv[1], vv[2], vv[3]), x);
+              const float sc[8] = {__uint_as_float(s0[0]), __uint_as_float(s0[1]), __uint_as_float(s0[2]), __uint_as_float(s0[3]),
+                                   __uint_as_float(s1[0]), __uint_as_float(s1[1]), __uint_as_float(s1[2]), __uint_as_float(s1[3])};
+              const float sh[8] = {__uint_as_float(h0[0]), __uint_as_float(h0[1]), __uint_as_float(h0[2]), __uint_as_float(h0[3]),
+                                   __uint_as_float(h1[0]), __uint_as_float(h1[1]), __uint_as_float(h1[2]), __uint_as_float(h1[3])};
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const float zv = x[q] * sc[q] + sh[q];
+                x[q] = (p.bna_relu && !(zv > 0.f)) ? 0.f : zv;
+              }
+              const uint4 o = pack8(x);
+              const u32x4 ov = {o.x, o.y, o.z, o.w};
+              asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(ov) : "memory");
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
         PP_STAMP(1)
         auto issue_dmas = [&](const int pos) __attribute__((always_inline)) {
           if (pos >= 0 && pos != (win_wave ? PP_WIN_WPOS : 1)) return;
@@ -796,6 +848,8 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   a.bnr_y = (const h16raw*)d.bnr_y; a.bnr_z = (const h16raw*)d.bnr_z;
   a.bnr_mean = d.bnr_mean; a.bnr_rstd = d.bnr_rstd; a.bnr_scale = d.bnr_scale; a.bnr_shift = d.bnr_shift;
   a.bnr_relu = d.bnr_relu; a.bnr_partials = d.bnr_partials;
+  const bool bna = d.a_bn_scale != nullptr;
+  a.bna_scale = d.a_bn_scale; a.bna_shift = d.a_bn_shift; a.bna_relu = d.a_bn_relu;
   a.a_bytes = (unsigned)((((long long)d.M - 1) * gg.cstride + gg.cg) * 2);
   const long long b_bytes = (((long long)d.b_rows - 1) * d.ldb + d.K) * 2;
   if (b_bytes <= 0 || b_bytes >= 0x40000000LL) { pp_set_error("pp_igemm: weight matrix too large for the window kernel"); return PP_ERR_INVALID; }
@@ -813,6 +867,17 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
       return PP_OK;
     }
   }
+  if (bna) {
+    if constexpr (TW && CC == 48 && WN == 4) {
+      if (d.residual || gg.cg > 160 || d.bnr_partials) { pp_set_error("pp_igemm: fused BatchNorm apply: no residual, no backward sums, <= 160 channels"); return PP_ERR_INVALID; }
+      hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+      PP_LAUNCH_CHECK();
+      return PP_OK;
+    } else {
+      pp_set_error("pp_igemm: fused BatchNorm apply is built for the temporal window kernel with 48-channel chunks only");
+      return PP_ERR_INVALID;
+    }
+  }
   if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
   else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
   PP_LAUNCH_CHECK();
@@ -827,18 +892,33 @@ extern "C" int pp_debug_win_stamps(void* host_out) {
 }
 #endif
 
+// temporal (3,1,1) stride-1 convs with 4, 8, 16 or 32 frames: 256-row tiles = all frames of 64 / 32 / 16 / 8 positions
+static bool tw_shape_ok(const pp_igemm_desc& d) {
+  const pp_gather& g = d.g;
+  const bool conv = g.mode == PP_CONV_FWD || g.mode == PP_CONV_DGRAD;
+  const int pb = (g.Gt == 4 || g.Gt == 8 || g.Gt == 16 || g.Gt == 32) ? 256 / g.Gt : 0;
+  return conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && d.drop_p == 0.f &&
+         !d.Cpre && !d.omap && g.kt == 3 && g.kh == 1 && g.kw == 1 && g.st == 1 && g.sh == 1 && g.sw == 1 &&
+         g.pt == 1 && g.ph == 0 && g.pw == 0 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && pb > 0 &&
+         (g.Gh * g.Gw) % pb == 0 && d.K == 3 * g.cg && d.M % 256 == 0 &&
+         (long long)d.M * g.cstride < 0x7f000000LL && (!d.residual || d.ldr % 8 == 0);
+}
+
+// Would pp_igemm apply a producer BatchNorm (a_bn_scale / a_bn_shift) for this problem?  (the temporal form from 48-channel
+// chunks with at most 64 output columns: the layer-1 temporal convs and the stem's)
+int pp_igemm_abn_ok(const pp_igemm_desc& d) {
+  const pp_gather& g = d.g;
+  const int n16 = (d.N + 15) / 16;
+  return pp_opt_win_igemm && (long long)d.M >= pp_opt_win_igemm && pp_opt_win_temporal && g.mode == PP_CONV_FWD && tw_shape_ok(d) &&
+         !d.residual && !d.bnr_partials && (g.cg == 48 || g.cg == 144) && n16 <= 4;
+}
+
 // PP_OK if the window kernel took the problem, 1 if the shape is not one it handles (caller falls through), < 0 on error.
 // `d` has been validated by pp_igemm.
 int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
   const pp_gather& g = d.g;
   const bool conv = g.mode == PP_CONV_FWD || g.mode == PP_CONV_DGRAD;
-  // temporal (3,1,1) stride-1 convs with 4, 8, 16 or 32 frames: 256-row tiles = all frames of 64 / 32 / 16 / 8 positions
-  const int pb = (g.Gt == 4 || g.Gt == 8 || g.Gt == 16 || g.Gt == 32) ? 256 / g.Gt : 0;
-  const bool tw_ok = pp_opt_win_temporal && conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && d.drop_p == 0.f &&
-                     !d.Cpre && !d.omap && g.kt == 3 && g.kh == 1 && g.kw == 1 && g.st == 1 && g.sh == 1 && g.sw == 1 &&
-                     g.pt == 1 && g.ph == 0 && g.pw == 0 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && pb > 0 &&
-                     (g.Gh * g.Gw) % pb == 0 && d.K == 3 * g.cg && d.M % 256 == 0 &&
-                     (long long)d.M * g.cstride < 0x7f000000LL && (!d.residual || d.ldr % 8 == 0);
+  const bool tw_ok = pp_opt_win_temporal && tw_shape_ok(d);
   if (tw_ok) {
     // resident weights: every K-step of a tile has its own ring slot (3 per channel chunk), one column block
     const int n16 = (d.N + 15) / 16;

@@ -16,6 +16,7 @@ extern int pp_opt_ring_wgrad;
 extern int pp_opt_sw_wgrad;
 int pp_wgrad_sw_try(const pp_wgrad_desc& d, hipStream_t s);
 int pp_wgrad_tw_try(const pp_wgrad_desc& d, hipStream_t s, bool force);
+bool pp_wgrad_tw_ok(const pp_wgrad_desc& d, bool force);
 
 namespace {
 
@@ -685,6 +686,18 @@ int launch_ring(const pp_wgrad_desc& d, hipStream_t s) {
 
 }  // namespace
 
+// x_bn_scale / x_bn_shift: only the temporal sliding-window kernel applies a producer BatchNorm to X
+static bool xbn_ok(const pp_wgrad_desc& d) {
+  return pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad && pp_wgrad_tw_ok(d, pp_opt_sw_wgrad == 1);
+}
+extern "C" int pp_wgrad_xbn_supported(const pp_wgrad_desc* dp) {
+  if (!dp) return 0;
+  pp_wgrad_desc d = *dp;
+  if (d.nbatch <= 0) d.nbatch = 1;
+  if (d.M <= 0 || d.Ni <= 0 || d.Kj <= 0 || d.g.mode != PP_CONV_FWD || pp_validate_gather(d.g, d.Kj, "pp_wgrad_xbn_supported") != PP_OK) return 0;
+  return xbn_ok(d) ? 1 : 0;
+}
+
 extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
   PP_CHECK_ARG(dp != nullptr, "pp_wgrad: null descriptor");
   pp_wgrad_desc d = *dp;
@@ -709,6 +722,12 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
                  "pp_wgrad: gathered tensor >= 2^31 elements or M not a multiple of Rt*Rh*Rw");
   }
   hipStream_t s = (hipStream_t)stream;
+  if (d.x_bn_scale || d.x_bn_shift) {
+    PP_CHECK_ARG(d.x_bn_scale && d.x_bn_shift && xbn_ok(d),
+                 "pp_wgrad: x_bn_scale / x_bn_shift (BatchNorm apply of X's producer) is not available for this problem: "
+                 "ask pp_wgrad_xbn_supported first");
+    return pp_wgrad_tw_try(d, s, pp_opt_sw_wgrad == 1);
+  }
   if (pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad) {   // (1,3,3) stride-1 convs: window along m
     const int rc_sw = pp_wgrad_sw_try(d, s);
     if (rc_sw != 1) return rc_sw;

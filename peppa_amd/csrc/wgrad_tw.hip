@@ -69,12 +69,15 @@ struct TwGeom {
   int cstride, cg;      // X row stride (elements), channels per tap in dW's layout
 };
 
-template <int WI>
+// BNA: X is the raw output y of a BatchNorm unit; every X block gets z = relu?(y * scale + shift) applied once, in LDS,
+// after it has landed and before its first use (pp_wgrad_desc.x_bn_*): the activated tensor is never materialised.
+template <int WI, bool BNA>
 __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const h16raw* __restrict__ X, const h16raw* __restrict__ dY,
                                                           float* __restrict__ dW, const TwGeom g, const int Ni,
                                                           const int ldy, const int ldw, const int nblk_i,
                                                           const int nblk_c, const int steps_per_split,
-                                                          const int xcd_remap) {
+                                                          const int xcd_remap, const float* __restrict__ bn_scale,
+                                                          const float* __restrict__ bn_shift, const int bn_relu) {
   constexpr int TI = 16 * WI;
   constexpr int PS = (WI & 1) ? TI * 2 : TI * 2 + 32;
   constexpr int PSLOT = MS * PS;
@@ -220,6 +223,40 @@ __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const h16raw* __restric
     }
   };
 
+  // ---- BNA: a block is 64 rows x 18 octets of 8 channels = 1152 16-byte chunks, two per thread; thread t keeps octet
+  // t % 18 (576 = 32 x 18), so its sixteen parameters live in registers.  Rows past the frame and channels past cg hold
+  // zeros that the pass may turn into relu(shift): their dY rows / dW columns are zero / unwritten.
+  float bsc[8], bsh[8];
+  const int b_c8 = tid % (CB / 8), b_row = tid / (CB / 8);
+  if (BNA) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + b_c8 * 8 + q;
+      bsc[q] = c < g.cg ? bn_scale[c] : 0.f;
+      bsh[q] = c < g.cg ? bn_shift[c] : 0.f;
+    }
+  }
+  auto bn_block = [&](const int sx) __attribute__((always_inline)) {     // X block of absolute step sx, in place
+    const unsigned base = lds0 + (unsigned)(((sx + NXSLOT) % NXSLOT) * XSLOT + b_c8 * 16);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      // (inline asm: plain LDS accesses make hipcc wait for the LDS-DMAs in flight first)
+      const unsigned a = base + (unsigned)((b_row + 32 * k) * XS);
+      u32x4 vv;
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vv) : "v"(a) : "memory");
+      float x[8];
+      unpack8(make_uint4(vv[0], vv[1], vv[2], vv[3]), x);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float zv = x[q] * bsc[q] + bsh[q];
+        x[q] = (bn_relu && !(zv > 0.f)) ? 0.f : zv;
+      }
+      const uint4 o = pack8(x);
+      const u32x4 ov = {o.x, o.y, o.z, o.w};
+      asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(ov) : "memory");
+    }
+  };
+
   // ---- prologue: X blocks s_begin - 1 .. s_begin + 2, dY steps s_begin, s_begin + 1 -----------------------------------
   dma_pair(0, s_begin - 1, false);
   dma_pair(0, s_begin, false);
@@ -227,10 +264,19 @@ __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const h16raw* __restric
   dma_pair(s_begin + 1, s_begin + 2, true);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (BNA) {                      // blocks s_begin - 1 and s_begin; block s + 1 follows at the start of iteration s
+    bn_block(s_begin - 1);
+    bn_block(s_begin);
+  }
   // ---- main loop.  Iteration s: issue dY step s + 2 and X block s + 3 (its slot held block s - 2), multiply step s,
   // wait for everything issued before this iteration, barrier. ----------------------------------------------------------
   for (int s = s_begin; s < s_end; ++s) {
     dma_pair(s + 2, s + 3, true);
+    if (BNA) {                    // (block s + 1 landed before the barrier that ended iteration s - 1)
+      bn_block(s + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     compute(s);
     wait_vmcnt_dyn(npiece);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -288,17 +334,20 @@ int launch_tw(const pp_wgrad_desc& d, hipStream_t s) {
   const int sps = (g.NS + msplit - 1) / msplit;
   msplit = (g.NS + sps - 1) / sps;
   dim3 grid((unsigned)(tiles * msplit), 1, 1), block(NT);
-  hipLaunchKernelGGL((wgrad_tw_kernel<WI>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
-                     d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad);
+  if (d.x_bn_scale)
+    hipLaunchKernelGGL((wgrad_tw_kernel<WI, true>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
+                       d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad, d.x_bn_scale, d.x_bn_shift, d.x_bn_relu);
+  else
+    hipLaunchKernelGGL((wgrad_tw_kernel<WI, false>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
+                       d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad, (const float*)nullptr, (const float*)nullptr, 0);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
 
 }  // namespace
 
-// PP_OK if the temporal sliding-window kernel took the problem, 1 if the shape is not one it handles, < 0 on error.
-// `force` (tests: pp_set_option("sw_wgrad", 1)) skips the is-it-worth-it rule.
-int pp_wgrad_tw_try(const pp_wgrad_desc& d, hipStream_t s, const bool force) {
+// Is `d` a problem the temporal sliding-window kernel takes?  (`force`: without the is-it-worth-it rule)
+bool pp_wgrad_tw_ok(const pp_wgrad_desc& d, const bool force) {
   const pp_gather& g = d.g;
   const long long frame = (long long)g.Gh * g.Gw;
   const bool shape_ok = g.mode == PP_CONV_FWD && d.nbatch == 1 && !d.dbias && g.kt == 3 && g.kh == 1 && g.kw == 1 &&
@@ -306,11 +355,17 @@ int pp_wgrad_tw_try(const pp_wgrad_desc& d, hipStream_t s, const bool force) {
                         g.Gh == g.Rh && g.Gw == g.Rw && g.cg >= 96 && g.cg % 16 == 0 && d.Kj == 3 * g.cg && d.Ni >= 64 &&
                         d.M % (g.Gt * frame) == 0 && (long long)d.M * g.cstride < 0x7fffffffLL &&
                         (long long)d.M * d.ldy < 0x7fffffffLL;
-  if (!shape_ok) return 1;
+  if (!shape_ok) return false;
   // worth it only where the 64-position blocks are mostly full and the clip is long enough that few steps lose a tap
   // (measured: layer 1/2 shapes 1.3-2.1x faster than the gather kernel, 14x14 / 7x7 frames with T <= 4 slower)
   const long long nhb = (frame + MS - 1) / MS;
-  if (!force && (frame * 10 < nhb * MS * 9 || g.Gt < 4)) return 1;
+  return force || !(frame * 10 < nhb * MS * 9 || g.Gt < 4);
+}
+
+// PP_OK if the temporal sliding-window kernel took the problem, 1 if the shape is not one it handles, < 0 on error.
+// `force` (tests: pp_set_option("sw_wgrad", 1)) skips the is-it-worth-it rule.
+int pp_wgrad_tw_try(const pp_wgrad_desc& d, hipStream_t s, const bool force) {
+  if (!pp_wgrad_tw_ok(d, force)) return 1;
   const int n16 = (d.Ni + 15) / 16;
   return n16 <= 4 ? launch_tw<4>(d, s) : launch_tw<8>(d, s);
 }

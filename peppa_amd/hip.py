@@ -140,7 +140,7 @@ def _wgrad_family(g):
 
 def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NONE, residual=None, ldr=0,
           Cpre=None, colstats=None, ldstat=0, nbatch=1, inner=1, a_s=(0, 0), b_s=(0, 0), c_s=(0, 0),
-          bias_s=(0, 0), omap=None, dropout=None, bnr=None):
+          bias_s=(0, 0), omap=None, dropout=None, bnr=None, bna=None):
     """bnr = (y, z or None, mean, rstd, scale, shift, relu, partials): BatchNorm-backward sums of the consumer of Cout taken
     in the epilogue (pp_igemm_desc.bnr_*).  Returns True when the dispatched kernel took them (else run bn_bwd_reduce)."""
     d = IGemmDesc()
@@ -161,6 +161,8 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
     if omap is not None:  # ((Ot, Oh, Ow), (scale t,h,w), (offset t,h,w))
         d.omap = 1
         (d.Ot, d.Oh, d.Ow), (d.os_t, d.os_h, d.os_w), (d.oo_t, d.oo_h, d.oo_w) = omap
+    if bna is not None:      # A is a BatchNorm unit's raw output y; the kernel reads relu?(y * scale + shift): (scale, shift, relu)
+        d.a_bn_scale, d.a_bn_shift, d.a_bn_relu = _p(bna[0], f32), _p(bna[1], f32), int(bna[2])
     if bnr is not None:
         y, z, mean, rstd, scale, shift, relu, partials = bnr
         d.bnr_y, d.bnr_z = _p(y, act16()), _p(z, act16())
@@ -172,8 +174,24 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
     return bnr is not None and rc[0] == 0
 
 
-def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0, dbias=None, dbias_s=0):
+def igemm_abn_supported(M, N, K, g, *, colstats=True):
+    """Would pp_igemm take a plain conv-forward of these sizes with a producer BatchNorm applied to A (igemm(bna=...))?"""
+    d = IGemmDesc()
+    d.M, d.N, d.K, d.g, d.b_rows, d.nbatch = M, N, K, g, N, 1
+    return bool(_lib.lib().pp_igemm_abn_supported(C.byref(d)))
+
+
+def wgrad_xbn_supported(M, Ni, Kj, g, ldy):
     d = WGradDesc()
+    d.M, d.Ni, d.Kj, d.g, d.ldy, d.nbatch = M, Ni, Kj, g, ldy, 1
+    return bool(_lib.lib().pp_wgrad_xbn_supported(C.byref(d)))
+
+
+def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0, dbias=None, dbias_s=0, x_bn=None):
+    """x_bn = (scale, shift, relu): X is a BatchNorm unit's raw output y, the kernel uses relu?(y * scale + shift)."""
+    d = WGradDesc()
+    if x_bn is not None:
+        d.x_bn_scale, d.x_bn_shift, d.x_bn_relu = _p(x_bn[0], f32), _p(x_bn[1], f32), int(x_bn[2])
     d.M, d.Ni, d.Kj, d.g = M, Ni, Kj, g
     d.X, d.dY, d.ldy, d.dW, d.ldw = _p(X, act16()), _p(dY, act16()), ldy, _p(dW, f32), ldw
     d.msplit, d.nbatch, d.x_s, d.dy_s, d.dw_s = msplit, nbatch, x_s, dy_s, dw_s

@@ -161,13 +161,24 @@ def _prep_conv_weights(w, geom, need_dgrad=True):
     return wf, wd
 
 
-def conv_fwd(x, geom, wf, *, stats=False, bias=None, act=H.ACT_NONE, out=None, pre=None):
-    """y[M][out_cstride] = conv(x); optional per-column partial sums for BatchNorm."""
+def can_fuse_bn_apply(geom):
+    """May the BatchNorm unit that FEEDS this convolution skip its apply pass -- i.e. do both the forward kernel and the
+    weight-gradient kernel this geometry dispatches to apply z = relu?(y * scale + shift) themselves, on their LDS windows
+    (pp_igemm_desc.a_bn_*, pp_wgrad_desc.x_bn_*)?  True for the layer-1 temporal convolutions of r2plus1d at the C2 shapes."""
+    if geom.groups != 1:
+        return False
+    return (H.igemm_abn_supported(geom.M, geom.out_cstride, geom.Kf, geom.g_fwd()) and
+            H.wgrad_xbn_supported(geom.M, geom.Co, geom.Kf, geom.g_fwd(), geom.out_cstride))
+
+
+def conv_fwd(x, geom, wf, *, stats=False, bias=None, act=H.ACT_NONE, out=None, pre=None, x_bn=None):
+    """y[M][out_cstride] = conv(x); optional per-column partial sums for BatchNorm.
+    x_bn = (scale, shift, relu): x is the raw output of a BatchNorm unit whose apply pass was skipped (can_fuse_bn_apply)."""
     y = out if out is not None else empty((geom.M, geom.out_cstride), act16(), x)
     partials = empty((geom.nblk, 2, geom.out_cstride), f32, x) if stats else None
     if geom.groups == 1:
         H.igemm(x, wf, y, geom.M, geom.out_cstride, geom.Kf, geom.g_fwd(), geom.Kf, geom.out_cstride,
-                b_rows=geom.Co, bias=bias, act=act, Cpre=pre, colstats=partials, ldstat=geom.out_cstride)
+                b_rows=geom.Co, bias=bias, act=act, Cpre=pre, colstats=partials, ldstat=geom.out_cstride, bna=x_bn)
     else:
         G = geom.groups
         H.igemm(x, wf, y, geom.M, geom.Cog, geom.Kf, geom.g_fwd(), geom.Kf, geom.out_cstride, b_rows=geom.Cog,
@@ -247,19 +258,19 @@ def conv_dgrad(dy, geom, wd, *, residual=None, consumer=None):
     return dx
 
 
-def conv_wgrad_raw(x, dy, geom):
+def conv_wgrad_raw(x, dy, geom, x_bn=None):
     """fp32 gradient in operand layout [Co][taps][cg_in]."""
     gw = zeros((geom.Co, geom.taps, geom.cg_in), f32, x)
     if geom.groups == 1:
-        H.wgrad(x, dy, gw, geom.M, geom.Co, geom.Kf, geom.g_fwd(), geom.out_cstride, geom.Kf)
+        H.wgrad(x, dy, gw, geom.M, geom.Co, geom.Kf, geom.g_fwd(), geom.out_cstride, geom.Kf, x_bn=x_bn)
     else:
         H.wgrad(x, dy, gw, geom.M, geom.Cog, geom.Kf, geom.g_fwd(), geom.out_cstride, geom.Kf, nbatch=geom.groups,
                 x_s=geom.Cig, dy_s=geom.Cog, dw_s=geom.Cog * geom.Kf)
     return gw
 
 
-def conv_wgrad(x, dy, geom, w_shape):
-    gw = conv_wgrad_raw(x, dy, geom)
+def conv_wgrad(x, dy, geom, w_shape, x_bn=None):
+    gw = conv_wgrad_raw(x, dy, geom, x_bn)
     dw = empty(w_shape, f32, x)
     H.unprep_conv_grad(gw, dw, geom.Co, geom.Cig, geom.taps, geom.cg_in)
     return dw
@@ -285,8 +296,9 @@ def _global_sums(partials, nblk, Cp):
     return tot
 
 
-def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momentum=0.1, update_running=True):
-    """z = relu?(bn(y) (+residual)); `bn` has .weight .bias .running_mean .running_var."""
+def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momentum=0.1, update_running=True, apply=True):
+    """z = relu?(bn(y) (+residual)); `bn` has .weight .bias .running_mean .running_var.
+    apply=False: statistics / scale / shift only, z = None -- the consumer applies them itself (can_fuse_bn_apply)."""
     C = bn.weight.numel()
     Cp = y.shape[1]
     sv = BNSaved()
@@ -302,6 +314,9 @@ def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momen
         H.bn_finalize(partials, nblk, Cp, count, C, Cp, bn.weight, bn.bias, eps, momentum,
                       bn.running_mean if update_running else None, bn.running_var if update_running else None,
                       sv.mean, sv.rstd, sv.scale, sv.shift, ws)
+    if not apply:
+        assert residual is None
+        return None, sv
     z = empty(y.shape, act16(), y)
     H.bn_apply(y, sv.scale, sv.shift, residual, relu, z, y.shape[0], Cp)
     return z, sv

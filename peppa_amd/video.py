@@ -216,34 +216,50 @@ def trunk_forward(net, x, norm_kind, training, save):
     return run_plan(net.units(), cur, (T, Hh, W), B, training, save, first=True)
 
 
+FUSE_BN_APPLY = True   # A/B switch (tools/ab_step.py fuse_bn_apply): see run_plan
+
+
 def run_plan(plan, cur, thw, B, training, save, first=False):
-    """Run a (partial) unit plan on a channels-last 16-bit activation [B*T*H*W][Cp]."""
+    """Run a (partial) unit plan on a channels-last 16-bit activation [B*T*H*W][Cp].
+
+    A unit whose activated output z = relu(bn(y)) feeds ONE convolution that can apply scale / shift / ReLU itself on its
+    LDS windows (layers.can_fuse_bn_apply: the layer-1 temporal convolutions of r2plus1d_18 at the C2 shapes) skips its
+    apply pass: the consumer -- and later its weight gradient -- reads the raw y, and z is never written (VERDICT r1
+    item 5 ii; bit-identical, one read and one write of the 144-channel tensor less per unit)."""
     tape = []
     block_in = block_thw = None
 
-    def run_unit(conv, bn, relu, inp, thw_in, residual=None, first=False):
+    def run_unit(conv, bn, relu, inp, thw_in, residual=None, first=False, x_bn=None, next_conv=None):
         geom = _geom(conv, B, thw_in, first)
         need_dgrad = save and not first
         wf, wd = L.prep_conv_weights(conv.weight, geom, need_dgrad=need_dgrad)
         # train mode: batch statistics from the conv epilogue; eval mode: running statistics
-        y, partials = L.conv_fwd(inp, geom, wf, stats=training)
+        y, partials = L.conv_fwd(inp, geom, wf, stats=training, x_bn=x_bn)
+        fuse = (FUSE_BN_APPLY and next_conv is not None and relu and residual is None and
+                L.can_fuse_bn_apply(_geom(next_conv, B, geom.out_thw, False)))
         z, sv = L.bn_fwd(y, partials, geom.nblk, geom.M, bn, relu=relu, residual=residual, eps=bn.eps,
-                         momentum=bn.momentum, update_running=training)
+                         momentum=bn.momentum, update_running=training, apply=not fuse)
         rec = None
         if save:
             rec = _Tape()
             rec.conv, rec.bn, rec.relu, rec.geom, rec.wd = conv, bn, relu, geom, wd
             rec.x, rec.y, rec.z, rec.sv, rec.first = inp, y, z, sv, first
+            rec.x_bn = x_bn
             rec.has_res = residual is not None
-        return z, geom.out_thw, rec
+        # (fused: the next unit reads y and applies (scale, shift, relu) itself)
+        return (y if fuse else z), geom.out_thw, rec, ((sv.scale, sv.shift, relu) if fuse else None)
 
-    for item in plan:
+    pending = None            # (scale, shift, relu) the next convolution must apply to its input
+    for k, item in enumerate(plan):
+        nxt = plan[k + 1] if k + 1 < len(plan) else None
         if item[0] == "unit":
             _, conv, bn, relu = item
-            cur, thw, rec = run_unit(conv, bn, relu, cur, thw, first=first)
+            next_conv = nxt[1] if nxt is not None and nxt[0] in ("unit", "block_last") else None
+            cur, thw, rec, pending = run_unit(conv, bn, relu, cur, thw, first=first, x_bn=pending, next_conv=next_conv)
             first = False
             tape.append(("unit", rec))
         elif item[0] == "maxpool":
+            assert pending is None
             T, Hh, W = thw
             Cp = cur.shape[1]
             Ho, Wo = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -252,6 +268,7 @@ def run_plan(plan, cur, thw, B, training, save, first=False):
             tape.append(("maxpool", (cur, B * T, Hh, W, Cp) if save else None))
             cur, thw = out, (T, Ho, Wo)
         elif item[0] == "block_begin":
+            assert pending is None
             block_in, block_thw = cur, thw
             tape.append(("block_begin", None))
         else:  # block_last
@@ -259,9 +276,10 @@ def run_plan(plan, cur, thw, B, training, save, first=False):
             ds_rec = None
             res = block_in
             if ds is not None:
-                res, _, ds_rec = run_unit(ds[0], ds[1], False, block_in, block_thw)
-            cur, thw, rec = run_unit(conv, bn, True, cur, thw, residual=res)
+                res, _, ds_rec, _ = run_unit(ds[0], ds[1], False, block_in, block_thw)
+            cur, thw, rec, pending = run_unit(conv, bn, True, cur, thw, residual=res, x_bn=pending)
             tape.append(("block_last", rec, ds_rec))
+    assert pending is None
     return cur, thw, tape
 
 
@@ -322,11 +340,11 @@ def trunk_backward(tape, dz, grads, overlap_wgrad=True):
             if side is not None:
                 side.wait_stream(main)              # dy (and everything before it) is ready
                 with torch.cuda.stream(side):
-                    grads[rec.conv.weight] = L.conv_wgrad(rec.x, dy, rec.geom, rec.conv.weight.shape)
+                    grads[rec.conv.weight] = L.conv_wgrad(rec.x, dy, rec.geom, rec.conv.weight.shape, x_bn=rec.x_bn)
                 dy.record_stream(side)              # keep the allocator from recycling them under the side stream
                 rec.x.record_stream(side)
             else:
-                grads[rec.conv.weight] = L.conv_wgrad(rec.x, dy, rec.geom, rec.conv.weight.shape)
+                grads[rec.conv.weight] = L.conv_wgrad(rec.x, dy, rec.geom, rec.conv.weight.shape, x_bn=rec.x_bn)
         dx = None
         if need_dx and not rec.first:
             dx = L.conv_dgrad(dy, rec.geom, rec.wd, residual=dgrad_residual, consumer=consumer)

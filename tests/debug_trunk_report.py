@@ -45,6 +45,7 @@ with torch.no_grad():
     for layer in (rv.layer1, rv.layer2, rv.layer3, rv.layer4):
         for blk in layer:
             cur = run_block(blk, cur)
+    V.FUSE_BN_APPLY = False      # (this report looks at every unit's activated output z)
     z, thw, tape = V.trunk_forward(net.video_encoder.video, batch.video.cuda(), "peppa", True, True)
 torch.cuda.synchronize()
 recs = []

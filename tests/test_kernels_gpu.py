@@ -1250,3 +1250,47 @@ def test_sync_bn_two_ranks_in_one_process_match_the_global_batch():
     # and the statistics really differ from per-rank ones
     local = L.bn_fwd(halves[0][0], *stats(halves[0][0]), M // 2, make_bn(), relu=True)[1]
     assert (local.mean - sv.mean).abs().max().item() > 0.1
+
+
+@pytest.mark.parametrize("case", [
+    # Ci, Co, B, T, H, W  -- temporal (3,1,1) convs fed by a BatchNorm unit whose apply pass the kernels do themselves
+    (144, 64, 2, 16, 8, 8),       # layer-1 width: three 48-channel chunks
+    (144, 64, 1, 8, 8, 16),       # 8 frames
+    (144, 64, 1, 16, 56, 56),     # layer-1 frame size
+])
+def test_fused_batchnorm_apply_matches_the_separate_pass(case):
+    """pp_igemm(a_bn_*) / pp_wgrad(x_bn_*): the temporal window kernel and the temporal sliding-window weight gradient apply
+    z = relu(y * scale + shift) to their LDS windows instead of reading a materialised z -- bit-identical outputs and
+    statistics (same bf16 z values, same products, same order), the weight gradient equal up to its fp32 atomics."""
+    Ci, Co, B, T, Hh, W = case
+    k, s, p = (3, 1, 1), (1, 1, 1), (1, 0, 0)
+    g = torch.Generator().manual_seed(5 * Ci + T + W)
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    try:
+        H.set_option("sw_wgrad", 1)         # (small test shapes: take the temporal kernel wherever it is built)
+        assert L.can_fuse_bn_apply(geom), "this shape should be one the fused path takes"
+        y = torch.randn(geom.Min, geom.in_cstride, generator=g).to(torch.bfloat16).to(DEV)
+        dy = torch.randn(geom.M, geom.out_cstride, generator=g).to(torch.bfloat16).to(DEV)
+        scale = (0.5 + torch.rand(geom.in_cstride, generator=g)).to(DEV)
+        shift = (0.3 * torch.randn(geom.in_cstride, generator=g)).to(DEV)
+        wf, _ = L.prep_conv_weights((torch.randn(Co, Ci, *k, generator=g) / math.sqrt(3 * Ci)).to(DEV), geom)
+        for relu in (True, False):
+            z = torch.empty_like(y)
+            H.bn_apply(y, scale, shift, None, relu, z, geom.Min, geom.in_cstride)
+            o_ref, st_ref = L.conv_fwd(z, geom, wf, stats=True)
+            o, st = L.conv_fwd(y, geom, wf, stats=True, x_bn=(scale, shift, relu))
+            gw_ref = L.conv_wgrad_raw(z, dy, geom)
+            gw = L.conv_wgrad_raw(y, dy, geom, x_bn=(scale, shift, relu))
+            torch.cuda.synchronize()
+            assert torch.equal(o, o_ref) and torch.equal(st, st_ref), relu
+            sc = gw_ref.abs().max().item()
+            assert (gw - gw_ref).abs().max().item() <= 2e-5 * sc + 1e-6, relu
+    finally:
+        H.set_option("sw_wgrad", H.SW_WGRAD_DEFAULT)
+    # a shape neither kernel takes says so, and asking anyway fails loudly instead of ignoring the parameters
+    other = L.ConvGeom(2, (4, 6, 6), 32, 48, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    assert not L.can_fuse_bn_apply(other)
+    wo, _ = L.prep_conv_weights(torch.randn(48, 32, 1, 3, 3, device=DEV), other)
+    xo = torch.randn(other.Min, other.in_cstride, device=DEV).to(torch.bfloat16)
+    with pytest.raises(Exception):
+        L.conv_fwd(xo, other, wo, x_bn=(torch.ones(other.in_cstride, device=DEV), torch.zeros(other.in_cstride, device=DEV), True))

@@ -33,6 +33,7 @@ from pig.execution import default_config
 from peppa_amd.data import synthetic_batch
 from peppa_amd import video as PV
 from peppa_amd import layers as L
+from peppa_amd import hip as H
 
 DEV = "cuda"
 
@@ -532,3 +533,45 @@ def test_optimizer_keeps_a_step_count_per_tensor():
             assert d <= 1e-6 + 1e-5 * pc.abs().max().item(), (i, step, d)
     assert [optim.state[p]["step"] for p in params] == [5, 5, 5, 4, 5]
     assert optim.get_lr()[3] != optim.get_lr()[0]
+
+
+def test_fused_batchnorm_apply_leaves_the_video_tower_unchanged():
+    """video.FUSE_BN_APPLY (the layer-1 temporal convs and their weight gradients apply the preceding BatchNorm + ReLU on
+    their own LDS windows, the activated mid tensors are never written): embeddings bit-identical to the unfused run,
+    gradients equal up to the fp32 atomics of the weight-gradient kernels; and the fused run really skipped the passes."""
+    cfg = make_cfg()
+    torch.manual_seed(3)
+    net = pig.models.PeppaPig(cfg).to(DEV).train()
+    enc = net.video_encoder
+    x = torch.rand(2, 3, 16, 64, 64, generator=torch.Generator().manual_seed(9)).to(DEV)     # layer 1: 32 x 32 positions
+    calls = {"n": 0}
+    real_apply = H.bn_apply
+
+    def counting_apply(*a, **k):
+        calls["n"] += 1
+        return real_apply(*a, **k)
+
+    outs = {}
+    state = copy.deepcopy(net.state_dict())       # (BatchNorm running statistics move with every forward)
+    try:
+        H.bn_apply = counting_apply
+        for fuse in (False, "again", True):      # ("again": a second unfused run, the yardstick for the float atomics)
+            net.load_state_dict(state)
+            PV.FUSE_BN_APPLY = fuse is True
+            calls["n"] = 0
+            net.zero_grad(set_to_none=True)
+            v = enc(x)
+            (v * torch.linspace(-1, 1, v.numel(), device=DEV).view_as(v)).sum().backward()
+            torch.cuda.synchronize()
+            outs[fuse] = (v.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None},
+                          calls["n"])
+    finally:
+        H.bn_apply = real_apply
+        PV.FUSE_BN_APPLY = True
+    assert outs[True][2] == outs[False][2] - 4, (outs[True][2], outs[False][2])     # four mid units of layer 1
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs["again"][0], outs[False][0])
+    for n, g0 in outs[False][1].items():
+        g1, g2 = outs[True][1][n], outs["again"][1][n]
+        scale = g0.abs().max().item() + 1e-12
+        noise = (g2 - g0).abs().max().item()
+        assert (g1 - g0).abs().max().item() <= 4 * noise + 1e-4 * scale, (n, (g1 - g0).abs().max().item(), noise, scale)
