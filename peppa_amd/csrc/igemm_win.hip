@@ -716,27 +716,36 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
           // z = relu(y * scale + shift) on the window that has just landed: 256 rows x six 8-channel octets, three per
           // thread; then every wave sees the activated rows (the masked taps' zero row is the conv's zero padding of z)
           constexpr int NOCT = BM * (CC / 8);
+          constexpr int NPT = (NOCT + NT - 1) / NT;
+          // (inline asm throughout: plain LDS accesses here make hipcc wait for every LDS-DMA in flight -- the windows of
+          // the next two phases -- before them and again in the K-steps.  All reads first, one wait.)
+          u32x4 vv[NPT], s0[NPT], s1[NPT], h0[NPT], h1[NPT];
+          unsigned adr[NPT];
 #pragma unroll
-          for (int k = 0; k < (NOCT + NT - 1) / NT; ++k) {
-            const int idx = tid + NT * k;
-            if (idx < NOCT) {
-              const int row = idx / (CC / 8), c8 = idx % (CC / 8);
-              // (inline asm throughout: plain LDS accesses here make hipcc wait for every LDS-DMA in flight -- the windows
-              // of the next two phases -- before them and again in the K-steps)
-              const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(win + row * XS + c8 * 16);
-              const unsigned t = (unsigned)(uintptr_t)(lds_ptr)(bna_tab + chunk * CC + c8 * 8);
-              u32x4 vv, s0, s1, h0, h1;
-              asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
-                           "ds_read_b128 %3, %6 offset:%7\n\tds_read_b128 %4, %6 offset:%8\n\ts_waitcnt lgkmcnt(0)"
-                           : "=&v"(vv), "=&v"(s0), "=&v"(s1), "=&v"(h0), "=&v"(h1)
-                           : "v"(a), "v"(t), "n"(BNA_CH * 4), "n"(BNA_CH * 4 + 16)
-                           : "memory");
+          for (int k = 0; k < NPT; ++k) {
+            const int idx = tid + NT * k < NOCT ? tid + NT * k : 0;       // (threads past the end re-read chunk 0, unused)
+            const int row = idx / (CC / 8), c8 = idx % (CC / 8);
+            adr[k] = (unsigned)(uintptr_t)(lds_ptr)(win + row * XS + c8 * 16);
+            const unsigned t = (unsigned)(uintptr_t)(lds_ptr)(bna_tab + chunk * CC + c8 * 8);
+            asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
+                         "ds_read_b128 %3, %6 offset:%7\n\tds_read_b128 %4, %6 offset:%8"
+                         : "=&v"(vv[k]), "=&v"(s0[k]), "=&v"(s1[k]), "=&v"(h0[k]), "=&v"(h1[k])
+                         : "v"(adr[k]), "v"(t), "n"(BNA_CH * 4), "n"(BNA_CH * 4 + 16)
+                         : "memory");
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < NPT; ++k)
+            asm volatile("" : "+v"(vv[k]), "+v"(s0[k]), "+v"(s1[k]), "+v"(h0[k]), "+v"(h1[k]));
+#pragma unroll
+          for (int k = 0; k < NPT; ++k) {
+            if (tid + NT * k < NOCT) {
               float x[8];
-              unpack8(make_uint4(vv[0], vv[1], vv[2], vv[3]), x);
-              const float sc[8] = {__uint_as_float(s0[0]), __uint_as_float(s0[1]), __uint_as_float(s0[2]), __uint_as_float(s0[3]),
-                                   __uint_as_float(s1[0]), __uint_as_float(s1[1]), __uint_as_float(s1[2]), __uint_as_float(s1[3])};
-              const float sh[8] = {__uint_as_float(h0[0]), __uint_as_float(h0[1]), __uint_as_float(h0[2]), __uint_as_float(h0[3]),
-                                   __uint_as_float(h1[0]), __uint_as_float(h1[1]), __uint_as_float(h1[2]), __uint_as_float(h1[3])};
+              unpack8(make_uint4(vv[k][0], vv[k][1], vv[k][2], vv[k][3]), x);
+              const float sc[8] = {__uint_as_float(s0[k][0]), __uint_as_float(s0[k][1]), __uint_as_float(s0[k][2]), __uint_as_float(s0[k][3]),
+                                   __uint_as_float(s1[k][0]), __uint_as_float(s1[k][1]), __uint_as_float(s1[k][2]), __uint_as_float(s1[k][3])};
+              const float sh[8] = {__uint_as_float(h0[k][0]), __uint_as_float(h0[k][1]), __uint_as_float(h0[k][2]), __uint_as_float(h0[k][3]),
+                                   __uint_as_float(h1[k][0]), __uint_as_float(h1[k][1]), __uint_as_float(h1[k][2]), __uint_as_float(h1[k][3])};
 #pragma unroll
               for (int q = 0; q < 8; ++q) {
                 const float zv = x[q] * sc[q] + sh[q];
@@ -744,7 +753,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
               }
               const uint4 o = pack8(x);
               const u32x4 ov = {o.x, o.y, o.z, o.w};
-              asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(ov) : "memory");
+              asm volatile("ds_write_b128 %0, %1" ::"v"(adr[k]), "v"(ov) : "memory");
             }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

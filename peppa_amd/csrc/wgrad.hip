@@ -688,7 +688,7 @@ int launch_ring(const pp_wgrad_desc& d, hipStream_t s) {
 
 // x_bn_scale / x_bn_shift: only the temporal sliding-window kernel applies a producer BatchNorm to X
 static bool xbn_ok(const pp_wgrad_desc& d) {
-  return pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad && pp_wgrad_tw_ok(d, pp_opt_sw_wgrad == 1);
+  return pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad && d.Ni <= 64 && pp_wgrad_tw_ok(d, pp_opt_sw_wgrad == 1);
 }
 extern "C" int pp_wgrad_xbn_supported(const pp_wgrad_desc* dp) {
   if (!dp) return 0;

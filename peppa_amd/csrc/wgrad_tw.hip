@@ -26,7 +26,7 @@ constexpr int CB = 144;                // X channels per workgroup (9 column til
 constexpr int XS = CB * 2;             // X block row stride: 288 = 32 x 9 (odd) -> conflict-free tr reads
 constexpr int XSLOT = MS * XS;
 constexpr int XPIECES = XSLOT / 1024;  // 18
-constexpr int NXSLOT = 5, NPSLOT = 3;
+constexpr int NPSLOT = 3;
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -85,6 +85,10 @@ __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const h16raw* __restric
   static_assert(PSLOT % 1024 == 0, "dY slab = whole DMA pieces");
   constexpr int NPIECES = PPIECES + XPIECES;
   constexpr int NK = (NPIECES + NWV - 1) / NWV;
+  // X ring: blocks s - 1, s, s + 1 in use and two in flight; BNA: three in flight, so that block s + 2 has landed when
+  // iteration s starts and its BatchNorm pass can ride inside the iteration, published by the iteration's own barrier
+  constexpr int NXSLOT = BNA ? 6 : 5;
+  constexpr int XA = BNA ? 4 : 3;                  // the X block issued at iteration s is s + XA
   constexpr int X_BYTES = NXSLOT * XSLOT;
   constexpr int SMEM = X_BYTES + NPSLOT * PSLOT;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
@@ -238,12 +242,13 @@ __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const h16raw* __restric
   }
   auto bn_block = [&](const int sx) __attribute__((always_inline)) {     // X block of absolute step sx, in place
     const unsigned base = lds0 + (unsigned)(((sx + NXSLOT) % NXSLOT) * XSLOT + b_c8 * 16);
+    // (inline asm: plain LDS accesses make hipcc wait for the LDS-DMAs in flight first)
+    const unsigned a0 = base + (unsigned)(b_row * XS), a1 = a0 + (unsigned)(32 * XS);
+    u32x4 v0, v1;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      // (inline asm: plain LDS accesses make hipcc wait for the LDS-DMAs in flight first)
-      const unsigned a = base + (unsigned)((b_row + 32 * k) * XS);
-      u32x4 vv;
-      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vv) : "v"(a) : "memory");
+      const u32x4 vv = k ? v1 : v0;
       float x[8];
       unpack8(make_uint4(vv[0], vv[1], vv[2], vv[3]), x);
 #pragma unroll
@@ -253,31 +258,32 @@ __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const h16raw* __restric
       }
       const uint4 o = pack8(x);
       const u32x4 ov = {o.x, o.y, o.z, o.w};
-      asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(ov) : "memory");
+      asm volatile("ds_write_b128 %0, %1" ::"v"(k ? a1 : a0), "v"(ov) : "memory");
     }
   };
 
-  // ---- prologue: X blocks s_begin - 1 .. s_begin + 2, dY steps s_begin, s_begin + 1 -----------------------------------
+  // ---- prologue: X blocks s_begin - 1 .. s_begin + XA - 1, dY steps s_begin, s_begin + 1 ----------------------------
   dma_pair(0, s_begin - 1, false);
   dma_pair(0, s_begin, false);
   dma_pair(s_begin, s_begin + 1, true);
   dma_pair(s_begin + 1, s_begin + 2, true);
+  if (BNA) dma_pair(0, s_begin + 3, false);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (BNA) {                      // blocks s_begin - 1 and s_begin; block s + 1 follows at the start of iteration s
+  if (BNA) {                      // blocks s_begin - 1 .. s_begin + 1; block s + 2 follows inside iteration s
     bn_block(s_begin - 1);
     bn_block(s_begin);
+    bn_block(s_begin + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
-  // ---- main loop.  Iteration s: issue dY step s + 2 and X block s + 3 (its slot held block s - 2), multiply step s,
-  // wait for everything issued before this iteration, barrier. ----------------------------------------------------------
+  // ---- main loop.  Iteration s: issue dY step s + 2 and X block s + XA (its slot held block s - 2), multiply step s, [BNA: activate
+  // block s + 2, which landed before the barrier that ended iteration s - 1 and is first read at step s + 1],
+  // wait for everything issued before this iteration, barrier. --------------------------------------------------------
   for (int s = s_begin; s < s_end; ++s) {
-    dma_pair(s + 2, s + 3, true);
-    if (BNA) {                    // (block s + 1 landed before the barrier that ended iteration s - 1)
-      bn_block(s + 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    dma_pair(s + 2, s + XA, true);
     compute(s);
+    if (BNA) bn_block(s + 2);       // (behind the step's MFMAs: its LDS round trip and VALU work run while they drain)
     wait_vmcnt_dyn(npiece);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -334,10 +340,15 @@ int launch_tw(const pp_wgrad_desc& d, hipStream_t s) {
   const int sps = (g.NS + msplit - 1) / msplit;
   msplit = (g.NS + sps - 1) / sps;
   dim3 grid((unsigned)(tiles * msplit), 1, 1), block(NT);
-  if (d.x_bn_scale)
-    hipLaunchKernelGGL((wgrad_tw_kernel<WI, true>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
-                       d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad, d.x_bn_scale, d.x_bn_shift, d.x_bn_relu);
-  else
+  if (d.x_bn_scale) {
+    if constexpr (WI == 4) {      // (64 rows of dW: the six-slot X ring does not fit beside the dY ring of 128)
+      hipLaunchKernelGGL((wgrad_tw_kernel<WI, true>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
+                         d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad, d.x_bn_scale, d.x_bn_shift, d.x_bn_relu);
+    } else {
+      pp_set_error("pp_wgrad: x_bn_scale / x_bn_shift need Ni <= 64 in the temporal sliding-window kernel");
+      return PP_ERR_INVALID;
+    }
+  } else
     hipLaunchKernelGGL((wgrad_tw_kernel<WI, false>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
                        d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad, (const float*)nullptr, (const float*)nullptr, 0);
   PP_LAUNCH_CHECK();
