@@ -363,12 +363,13 @@ bool pp_wgrad_tw_ok(const pp_wgrad_desc& d, const bool force) {
   const long long frame = (long long)g.Gh * g.Gw;
   const bool shape_ok = g.mode == PP_CONV_FWD && d.nbatch == 1 && !d.dbias && g.kt == 3 && g.kh == 1 && g.kw == 1 &&
                         g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 1 && g.ph == 0 && g.pw == 0 && g.Gt == g.Rt &&
-                        g.Gh == g.Rh && g.Gw == g.Rw && g.cg >= 96 && g.cg % 16 == 0 && d.Kj == 3 * g.cg && d.Ni >= 64 &&
+                        g.Gh == g.Rh && g.Gw == g.Rw && g.cg >= 48 && g.cg % 16 == 0 && d.Kj == 3 * g.cg && d.Ni >= 64 &&
                         d.M % (g.Gt * frame) == 0 && (long long)d.M * g.cstride < 0x7fffffffLL &&
                         (long long)d.M * d.ldy < 0x7fffffffLL;
   if (!shape_ok) return false;
   // worth it only where the 64-position blocks are mostly full and the clip is long enough that few steps lose a tap
-  // (measured: layer 1/2 shapes 1.3-2.1x faster than the gather kernel, 14x14 / 7x7 frames with T <= 4 slower)
+  // (measured: layer 1/2 shapes 1.3-2.1x faster than the gather kernel, 14x14 / 7x7 frames with T <= 4 slower; the stem's
+  // 48 channels fill a third of a 144-channel block and still run 292 vs 333 us)
   const long long nhb = (frame + MS - 1) / MS;
   return force || !(frame * 10 < nhb * MS * 9 || g.Gt < 4);
 }

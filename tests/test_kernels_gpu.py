@@ -1257,6 +1257,7 @@ def test_sync_bn_two_ranks_in_one_process_match_the_global_batch():
     (144, 64, 2, 16, 8, 8),       # layer-1 width: three 48-channel chunks
     (144, 64, 1, 8, 8, 16),       # 8 frames
     (144, 64, 1, 16, 56, 56),     # layer-1 frame size
+    (45, 64, 2, 16, 8, 16),       # the stem: 45 channels in one 48-channel chunk (pad channels: scale = shift = 0)
 ])
 def test_fused_batchnorm_apply_matches_the_separate_pass(case):
     """pp_igemm(a_bn_*) / pp_wgrad(x_bn_*): the temporal window kernel and the temporal sliding-window weight gradient apply
@@ -1271,8 +1272,11 @@ def test_fused_batchnorm_apply_matches_the_separate_pass(case):
         assert L.can_fuse_bn_apply(geom), "this shape should be one the fused path takes"
         y = torch.randn(geom.Min, geom.in_cstride, generator=g).to(torch.bfloat16).to(DEV)
         dy = torch.randn(geom.M, geom.out_cstride, generator=g).to(torch.bfloat16).to(DEV)
+        y[:, Ci:] = 0
         scale = (0.5 + torch.rand(geom.in_cstride, generator=g)).to(DEV)
         shift = (0.3 * torch.randn(geom.in_cstride, generator=g)).to(DEV)
+        scale[Ci:] = 0      # (as pp_bn_finalize leaves the pad channels)
+        shift[Ci:] = 0
         wf, _ = L.prep_conv_weights((torch.randn(Co, Ci, *k, generator=g) / math.sqrt(3 * Ci)).to(DEV), geom)
         for relu in (True, False):
             z = torch.empty_like(y)

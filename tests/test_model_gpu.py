@@ -568,7 +568,7 @@ def test_fused_batchnorm_apply_leaves_the_video_tower_unchanged():
     finally:
         H.bn_apply = real_apply
         PV.FUSE_BN_APPLY = True
-    assert outs[True][2] == outs[False][2] - 4, (outs[True][2], outs[False][2])     # four mid units of layer 1
+    assert outs[True][2] == outs[False][2] - 5, (outs[True][2], outs[False][2])     # the stem's first unit + four mid units of layer 1
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs["again"][0], outs[False][0])
     for n, g0 in outs[False][1].items():
         g1, g2 = outs[True][1][n], outs["again"][1][n]
