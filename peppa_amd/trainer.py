@@ -172,7 +172,7 @@ class Trainer:
                 optim.zero_grad(set_to_none=True)
                 self.global_step += 1
                 if self.global_step % self.log_every == 0:
-                    log.info("step %d loss %.5f (%.1f s)", self.global_step, float(loss), time.time() - t0)
+                    log.info("step %d loss %.5f (%.1f s)", self.global_step, float(loss.detach()), time.time() - t0)
                 if self.max_steps is not None and self.global_step >= self.max_steps:
                     return True
                 if self.max_time_s is not None and time.time() - t0 > self.max_time_s:
