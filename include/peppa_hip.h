@@ -176,6 +176,19 @@ int pp_collate_rows(const void* items, int n, long long row_bytes, void* out, pp
  * pp_collate_video_u8 followed by pp_video_normalize_ndhwc without the fp32 batch in between */
 int pp_video_normalize_u8_ndhwc(const void* x, void* out, int B, int T, int H, int W,
                                 const float* mean3 /* HOST */, const float* std3 /* HOST */, pp_stream_t s);
+/* The same two with FOUR channels per pixel (3 real + 0): out [B*T*H*W][4].  Two pixels then share a 16-byte chunk, and a
+ * stride-2 first convolution over [W][4] is run as a stride-1 convolution over the pixel PAIRS [W/2][8] of the same
+ * memory with weights laid out by pp_prep_conv_weight_pairs: kernel width kw -> kwp = floor((kw-1-pw)/2) - floor(-pw/2) + 1
+ * pair taps (7 -> 4 at pw = 3), left padding pj = -floor(-pw/2) (2), output width forced to the original Wo (the
+ * gather's bounds check supplies the right-hand padding).  K of the (1,7,7) stem: 49 x 8 -> 28 x 8. */
+int pp_video_normalize_ndhwc4(const float* x, void* out, int B, int T, int H, int W,
+                              const float* mean3, const float* std3, pp_stream_t s);
+int pp_video_normalize_u8_ndhwc4(const void* x, void* out, int B, int T, int H, int W,
+                                 const float* mean3, const float* std3, pp_stream_t s);
+/* w fp32 [Co][Ci <= 4][kth][kw] -> out 16-bit [Co][kth * kwp][8]: element q * 4 + c of pair tap dj = w[co][c][a][2 (dj - pj) + q + pw]
+ * (0 outside the kernel row / for c >= Ci); and back for the gradient: g fp32 [Co][kth * kwp][8] -> dw [Co][Ci][kth][kw] */
+int pp_prep_conv_weight_pairs(const float* w, int Co, int Ci, int kth, int kw, int pw, void* out, pp_stream_t s);
+int pp_unprep_conv_grad_pairs(const float* g, int Co, int Ci, int kth, int kw, int pw, float* dw, pp_stream_t s);
 
 /* MaxPool2d(3, 2, 1) of torchvision resnet18 (static ImageEncoder, pig/models.py:181-186) on channels-last
  * bf16 [N][H][W][Cp]; the backward routes each window's gradient to its first maximum (PyTorch's rule) */

@@ -83,6 +83,10 @@ SIGNATURES = {
     "pp_collate_video_u8": [P, I, I, I, I, P, P],
     "pp_collate_rows": [P, I, L, P, P],
     "pp_video_normalize_u8_ndhwc": [P, P, I, I, I, I, C.POINTER(F), C.POINTER(F), P],
+    "pp_video_normalize_ndhwc4": [P, P, I, I, I, I, C.POINTER(F), C.POINTER(F), P],
+    "pp_video_normalize_u8_ndhwc4": [P, P, I, I, I, I, C.POINTER(F), C.POINTER(F), P],
+    "pp_prep_conv_weight_pairs": [P, I, I, I, I, I, P, P],
+    "pp_unprep_conv_grad_pairs": [P, I, I, I, I, I, P, P],
     "pp_maxpool3x3s2_fwd": [P, P, I, I, I, I, P],
     "pp_maxpool3x3s2_bwd": [P, P, P, I, I, I, I, P],
     "pp_partials_sum": [P, I, I, P, P, P],

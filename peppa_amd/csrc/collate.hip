@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void collate_rows_kernel(const long long* __re
 
 // uint8 [B][T][H][W][3] -> normalised bf16 [B*T*H*W][8] (channels 3..7 zero): the stem's input, same arithmetic as
 // video_norm_kernel on the fp32 batch ((x/255 - mean) * (1/std), RNE to bf16), so both routes give identical bits.
+template <int CPP>
 __global__ __launch_bounds__(256) void video_norm_u8_kernel(const uint8_t* __restrict__ x, h16raw* __restrict__ out,
                                                             long long npos, float m0, float m1, float m2, float i0,
                                                             float i1, float i2) {
@@ -95,14 +96,18 @@ __global__ __launch_bounds__(256) void video_norm_u8_kernel(const uint8_t* __res
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float f[8] = {(lut[px[k][0]] - m0) * i0, (lut[px[k][1]] - m1) * i1, (lut[px[k][2]] - m2) * i2, 0, 0, 0, 0, 0};
-        *(uint4*)(out + (q * 4 + k) * 8) = pack8(f);
+        const uint4 v = pack8(f);
+        if (CPP == 8) *(uint4*)(out + (q * 4 + k) * 8) = v;
+        else *(uint2*)(out + (q * 4 + k) * 4) = make_uint2(v.x, v.y);
       }
     }
   } else {
     GSTRIDE(i, npos) {
       float f[8] = {(lut[x[i * 3]] - m0) * i0, (lut[x[i * 3 + 1]] - m1) * i1, (lut[x[i * 3 + 2]] - m2) * i2,
                     0, 0, 0, 0, 0};
-      *(uint4*)(out + i * 8) = pack8(f);
+      const uint4 v = pack8(f);
+      if (CPP == 8) *(uint4*)(out + i * 8) = v;
+      else *(uint2*)(out + i * 4) = make_uint2(v.x, v.y);
     }
   }
 }
@@ -139,7 +144,17 @@ extern "C" int pp_video_normalize_u8_ndhwc(const void* x, void* out, int B, int 
   PP_CHECK_ARG(x && out && B > 0 && T > 0 && H > 0 && W > 0 && mean3 && std3, "pp_video_normalize_u8_ndhwc: sizes");
   PP_CHECK_ARG((((uintptr_t)x) & 3) == 0, "pp_video_normalize_u8_ndhwc: x must be 4-byte aligned");
   const long long npos = (long long)B * T * H * W;
-  hipLaunchKernelGGL(video_norm_u8_kernel, dim3(grid_x(npos / 4 + 1, 1)), dim3(256), 0, S_, (const uint8_t*)x,
+  hipLaunchKernelGGL(video_norm_u8_kernel<8>, dim3(grid_x(npos / 4 + 1, 1)), dim3(256), 0, S_, (const uint8_t*)x,
+                     (h16raw*)out, npos, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_video_normalize_u8_ndhwc4(const void* x, void* out, int B, int T, int H, int W, const float* mean3,
+                                            const float* std3, pp_stream_t s) {
+  PP_CHECK_ARG(x && out && B > 0 && T > 0 && H > 0 && W > 0 && mean3 && std3, "pp_video_normalize_u8_ndhwc4: sizes");
+  PP_CHECK_ARG((((uintptr_t)x) & 3) == 0, "pp_video_normalize_u8_ndhwc4: x must be 4-byte aligned");
+  const long long npos = (long long)B * T * H * W;
+  hipLaunchKernelGGL(video_norm_u8_kernel<4>, dim3(grid_x(npos / 4 + 1, 1)), dim3(256), 0, S_, (const uint8_t*)x,
                      (h16raw*)out, npos, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
   PP_LAUNCH_CHECK();
   return PP_OK;

@@ -179,14 +179,51 @@ __global__ __launch_bounds__(256) void transpose_kernel(const h16raw* __restrict
   }
 }
 
-// x fp32 [B][3][T][H][W] -> out bf16 [B][T][H][W][8]
+// x fp32 [B][3][T][H][W] -> out bf16 [B][T][H][W][CPP] (CPP = 8, or 4: two pixels per 16-byte chunk, see pp_prep_conv_weight_pairs)
+template <int CPP>
 __global__ void video_norm_kernel(const float* __restrict__ x, h16raw* __restrict__ out, long long npos, long long thw,
                                   float m0, float m1, float m2, float i0, float i1, float i2) {
   GSTRIDE(i, npos) {
     const long long b = i / thw, p = i % thw;
     const float* xp = x + b * 3 * thw + p;
     float f[8] = {(xp[0] - m0) * i0, (xp[thw] - m1) * i1, (xp[2 * thw] - m2) * i2, 0, 0, 0, 0, 0};
-    *(uint4*)(out + i * 8) = pack8(f);
+    const uint4 v = pack8(f);
+    if (CPP == 8) *(uint4*)(out + i * 8) = v;
+    else *(uint2*)(out + i * 4) = make_uint2(v.x, v.y);
+  }
+}
+// Stem weights for an input of PAIRED pixels.  A stride-2 conv over [W][4 channels] reads, for output column w, the
+// pixels 2 w + dw - pw; pixel pairs (2 j, 2 j + 1) are the 16-byte chunks [W/2][8] of the same memory, so it equals a
+// stride-1 conv over pairs j = w + dj - pj with kw' = dj_max - dj_min + 1 taps (7 -> 4): 8-channel chunks carry two real
+// pixels instead of one real pixel and five zeros, K = 49 x 8 -> 28 x 8 for the (1,7,7) stem.
+//   w [Co][Ci][kth][kw] fp32 -> out [Co][kth * kwp][8] 16-bit, element e = q * 4 + c of pair tap dj <- w[co][c][a][2 (dj - pj) + q + pw]
+__global__ void prep_conv_pairs_kernel(const float* __restrict__ w, int Co, int Ci, int kth, int kw, int pw, int kwp, int pj,
+                                       h16raw* __restrict__ out) {
+  GSTRIDE(i, (long long)Co * kth * kwp * 8) {
+    const int e = (int)(i & 7);
+    const long long t = i >> 3;
+    const int dj = (int)(t % kwp);
+    const long long t2 = t / kwp;
+    const int a = (int)(t2 % kth), co = (int)(t2 / kth);
+    const int q = e >> 2, c = e & 3;
+    const int dw = 2 * (dj - pj) + q + pw;
+    float v = 0.f;
+    if (c < Ci && dw >= 0 && dw < kw) v = w[(((long long)co * Ci + c) * kth + a) * kw + dw];
+    out[i] = f2h(v);
+  }
+}
+// ... and the way back for the gradient: g [Co][kth * kwp][8] fp32 -> dw [Co][Ci][kth][kw]
+__global__ void unprep_conv_pairs_kernel(const float* __restrict__ g, int Co, int Ci, int kth, int kw, int pw, int kwp, int pj,
+                                         float* __restrict__ dwt) {
+  GSTRIDE(i, (long long)Co * Ci * kth * kw) {
+    const int dw = (int)(i % kw);
+    const long long t = i / kw;
+    const int a = (int)(t % kth);
+    const long long t2 = t / kth;
+    const int c = (int)(t2 % Ci), co = (int)(t2 / Ci);
+    const int u = dw - pw + 2 * pj;          // = 2 dj + q
+    const int dj = u >> 1, q = u & 1;
+    dwt[i] = g[(((long long)co * kth + a) * kwp + dj) * 8 + q * 4 + c];
   }
 }
 
@@ -315,8 +352,42 @@ extern "C" int pp_video_normalize_ndhwc(const float* x, void* out, int B, int T,
                                         const float* std3, pp_stream_t s) {
   PP_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0 && mean3 && std3, "pp_video_normalize_ndhwc: sizes");
   const long long thw = (long long)T * H * W;
-  hipLaunchKernelGGL(video_norm_kernel, dim3(sgrid(B * thw)), dim3(256), 0, S_, x, (h16raw*)out, B * thw, thw, mean3[0],
+  hipLaunchKernelGGL(video_norm_kernel<8>, dim3(sgrid(B * thw)), dim3(256), 0, S_, x, (h16raw*)out, B * thw, thw, mean3[0],
                      mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_video_normalize_ndhwc4(const float* x, void* out, int B, int T, int H, int W, const float* mean3,
+                                         const float* std3, pp_stream_t s) {
+  PP_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0 && mean3 && std3, "pp_video_normalize_ndhwc4: sizes");
+  const long long thw = (long long)T * H * W;
+  hipLaunchKernelGGL(video_norm_kernel<4>, dim3(sgrid(B * thw)), dim3(256), 0, S_, x, (h16raw*)out, B * thw, thw, mean3[0],
+                     mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+// pair geometry of a stride-2 kernel row: taps dj_min .. dj_max of the pair index, see prep_conv_pairs_kernel
+static inline void pair_taps(int kw, int pw, int* kwp, int* pj) {
+  auto fl2 = [](int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); };
+  const int lo = fl2(-pw), hi = fl2(kw - 1 - pw);
+  *kwp = hi - lo + 1;
+  *pj = -lo;
+}
+extern "C" int pp_prep_conv_weight_pairs(const float* w, int Co, int Ci, int kth, int kw, int pw, void* out, pp_stream_t s) {
+  PP_CHECK_ARG(w && out && Co > 0 && Ci > 0 && Ci <= 4 && kth > 0 && kw > 0 && pw >= 0, "pp_prep_conv_weight_pairs: sizes (Ci <= 4)");
+  int kwp, pj;
+  pair_taps(kw, pw, &kwp, &pj);
+  hipLaunchKernelGGL(prep_conv_pairs_kernel, dim3(sgrid((long long)Co * kth * kwp * 8)), dim3(256), 0, S_, w, Co, Ci, kth, kw, pw,
+                     kwp, pj, (h16raw*)out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_unprep_conv_grad_pairs(const float* g, int Co, int Ci, int kth, int kw, int pw, float* dw, pp_stream_t s) {
+  PP_CHECK_ARG(g && dw && Co > 0 && Ci > 0 && Ci <= 4 && kth > 0 && kw > 0 && pw >= 0, "pp_unprep_conv_grad_pairs: sizes (Ci <= 4)");
+  int kwp, pj;
+  pair_taps(kw, pw, &kwp, &pj);
+  hipLaunchKernelGGL(unprep_conv_pairs_kernel, dim3(sgrid((long long)Co * Ci * kth * kw)), dim3(256), 0, S_, g, Co, Ci, kth, kw,
+                     pw, kwp, pj, dw);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

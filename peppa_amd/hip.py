@@ -254,10 +254,20 @@ def fill_f32(t, v):
 
 
 def video_normalize_ndhwc(x, out, mean3, std3):
+    """out [B*T*H*W][8], or [B*T*H*W][4] (paired-pixel stem, pp_prep_conv_weight_pairs) by the shape of `out`."""
     B, _, T, H, W = x.shape
     m = (C.c_float * 3)(*mean3)
     sd = (C.c_float * 3)(*std3)
-    call("pp_video_normalize_ndhwc", _p(x, f32), _p(out, act16()), B, T, H, W, m, sd, _s())
+    call("pp_video_normalize_ndhwc4" if out.shape[-1] == 4 else "pp_video_normalize_ndhwc", _p(x, f32), _p(out, act16()),
+         B, T, H, W, m, sd, _s())
+
+
+def prep_conv_weight_pairs(w, out, Co, Ci, kth, kw, pw):
+    call("pp_prep_conv_weight_pairs", _p(w, f32), Co, Ci, kth, kw, pw, _p(out, act16()), _s())
+
+
+def unprep_conv_grad_pairs(g, dw, Co, Ci, kth, kw, pw):
+    call("pp_unprep_conv_grad_pairs", _p(g, f32), Co, Ci, kth, kw, pw, _p(dw, f32), _s())
 
 
 def video_normalize_u8_ndhwc(x, out, mean3, std3):
@@ -267,7 +277,8 @@ def video_normalize_u8_ndhwc(x, out, mean3, std3):
         raise PeppaHipError(f"uint8 video must be contiguous (B,T,H,W,3), got {tuple(x.shape)} {x.dtype}")
     m = (C.c_float * 3)(*mean3)
     sd = (C.c_float * 3)(*std3)
-    call("pp_video_normalize_u8_ndhwc", x.data_ptr(), _p(out, act16()), B, T, H, W, m, sd, _s())
+    call("pp_video_normalize_u8_ndhwc4" if out.shape[-1] == 4 else "pp_video_normalize_u8_ndhwc", x.data_ptr(),
+         _p(out, act16()), B, T, H, W, m, sd, _s())
 
 
 def collate_video_u8(table, n, Tmax, H, W, out):

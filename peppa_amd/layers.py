@@ -69,12 +69,13 @@ def zeros(shape, dtype, like):
 class ConvGeom:
     """Geometry of one convolution on a channels-last tensor [B][Ti][Hi][Wi][cstride]."""
 
-    def __init__(self, B, in_thw, Ci, Co, k, s, p, groups=1, in_cstride=None, out_cstride=None, cg_in=None, To=None):
+    def __init__(self, B, in_thw, Ci, Co, k, s, p, groups=1, in_cstride=None, out_cstride=None, cg_in=None, To=None, Wo=None):
         self.B, self.Ci, self.Co, self.k, self.s, self.p, self.groups = B, Ci, Co, tuple(k), tuple(s), tuple(p), groups
         self.Ti, self.Hi, self.Wi = in_thw
         self.To = To if To is not None else (self.Ti + 2 * p[0] - k[0]) // s[0] + 1  # To override: pos-conv drops its last frame
         self.Ho = (self.Hi + 2 * p[1] - k[1]) // s[1] + 1
-        self.Wo = (self.Wi + 2 * p[2] - k[2]) // s[2] + 1
+        self.Wo = Wo if Wo is not None else (self.Wi + 2 * p[2] - k[2]) // s[2] + 1  # Wo override: paired-pixel stem
+        self.pairs = None     # (Ci, kw, pw) of the ORIGINAL convolution when this is its paired-pixel form (ConvGeom.paired_stem)
         self.taps = k[0] * k[1] * k[2]
         self.Cig, self.Cog = Ci // groups, Co // groups
         # channels read per tap / written per group
@@ -91,6 +92,24 @@ class ConvGeom:
     @property
     def out_thw(self):
         return (self.To, self.Ho, self.Wo)
+
+    @staticmethod
+    def paired_stem(B, in_thw, Ci, Co, k, s, p):
+        """A first convolution with <= 4 input channels and stride 2 along W, over an input stored with FOUR channels per
+        pixel: the pixel pairs (2 j, 2 j + 1) are 8-channel chunks [W/2][8] of the same memory, and the convolution is the
+        stride-1 one over pairs with kwp = 4 (for kw = 7, pw = 3) taps per kernel row (include/peppa_hip.h,
+        pp_prep_conv_weight_pairs).  An 8-channel chunk then carries two real pixels instead of one and five zeros: the
+        reduce length of the (1,7,7) stem drops from 49 x 8 to 28 x 8.  None if the shape does not pair."""
+        T, Hh, W = in_thw
+        if Ci > 4 or s[2] != 2 or W % 2 != 0:
+            return None
+        kw, pw = k[2], p[2]
+        lo, hi = (-pw) // 2, (kw - 1 - pw) // 2            # (floor division)
+        kwp, pj = hi - lo + 1, -lo
+        wo = (W + 2 * pw - kw) // 2 + 1
+        g = ConvGeom(B, (T, Hh, W // 2), 8, Co, (k[0], k[1], kwp), (s[0], s[1], 1), (p[0], p[1], pj), in_cstride=8, cg_in=8, Wo=wo)
+        g.pairs = (Ci, kw, pw)
+        return g
 
     def g_fwd(self):
         return H.gather_conv(H.CONV_FWD, (self.To, self.Ho, self.Wo), (self.Ti, self.Hi, self.Wi), self.k, self.s,
@@ -139,8 +158,19 @@ def cached_operands(key, params, build):
 
 def prep_conv_weights(w, geom, need_dgrad=True):
     """fp32 master [Co][Ci/groups][taps...] -> 16-bit operands (forward, dgrad)."""
+    if geom.pairs is not None:
+        assert not need_dgrad, "a paired-pixel stem is a first layer: no data gradient"
+        key = ("conv-pairs", geom.Co, geom.k, geom.pairs)
+        return cached_operands(key, (w,), lambda: (_prep_conv_weights_pairs(w, geom), None))
     key = ("conv", geom.Co, geom.Cig, geom.taps, geom.cg_in, geom.cg_out, geom.groups, geom.Ci, bool(need_dgrad))
     return cached_operands(key, (w,), lambda: _prep_conv_weights(w, geom, need_dgrad))
+
+
+def _prep_conv_weights_pairs(w, geom):
+    Ci, kw, pw = geom.pairs
+    wf = empty((geom.Co, geom.taps, 8), act16(), w)
+    H.prep_conv_weight_pairs(w, wf, geom.Co, Ci, geom.k[0] * geom.k[1], kw, pw)
+    return wf
 
 
 def _prep_conv_weights(w, geom, need_dgrad=True):
@@ -272,7 +302,11 @@ def conv_wgrad_raw(x, dy, geom, x_bn=None):
 def conv_wgrad(x, dy, geom, w_shape, x_bn=None):
     gw = conv_wgrad_raw(x, dy, geom, x_bn)
     dw = empty(w_shape, f32, x)
-    H.unprep_conv_grad(gw, dw, geom.Co, geom.Cig, geom.taps, geom.cg_in)
+    if geom.pairs is not None:
+        Ci, kw, pw = geom.pairs
+        H.unprep_conv_grad_pairs(gw, dw, geom.Co, Ci, geom.k[0] * geom.k[1], kw, pw)
+    else:
+        H.unprep_conv_grad(gw, dw, geom.Co, geom.Cig, geom.taps, geom.cg_in)
     return dw
 
 

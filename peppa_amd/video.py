@@ -191,10 +191,23 @@ def _t3(v):
     return tuple(v) if len(v) == 3 else (1,) + tuple(v)
 
 
+PAIRED_STEM = True   # A/B switch: the first convolution over pixel pairs (layers.ConvGeom.paired_stem)
+
+
+def stem_pairs(conv, thw):
+    """Does the first convolution `conv` run over pixel pairs for an input of (T, H, W)?  Then the normalised input is
+    written with four channels per pixel (trunk_forward) and _geom(first=True) gives the paired geometry."""
+    pad = conv.padding if len(conv.padding) == 3 else (0,) + tuple(conv.padding)
+    return PAIRED_STEM and L.ConvGeom.paired_stem(1, thw, conv.in_channels, conv.out_channels, _t3(conv.kernel_size),
+                                                  _t3(conv.stride), pad) is not None
+
+
 def _geom(conv, B, thw, first=False):
     ci = conv.in_channels
-    kw = dict(in_cstride=8, cg_in=8) if first else {}
     pad = conv.padding if len(conv.padding) == 3 else (0,) + tuple(conv.padding)
+    if first and stem_pairs(conv, thw):
+        return L.ConvGeom.paired_stem(B, thw, ci, conv.out_channels, _t3(conv.kernel_size), _t3(conv.stride), pad)
+    kw = dict(in_cstride=8, cg_in=8) if first else {}
     return L.ConvGeom(B, thw, ci, conv.out_channels, _t3(conv.kernel_size), _t3(conv.stride), pad, **kw)
 
 
@@ -202,18 +215,28 @@ class _Tape:
     pass
 
 
-def trunk_forward(net, x, norm_kind, training, save):
-    """x fp32 [B][3][T][H][W] (or uint8 [B][T][H][W][3]) -> (z 16-bit [B*T'*H'*W'][512], (T',H',W'), tape)."""
+def normalized_input(x, norm_kind, first_conv):
+    """x fp32 [B][3][T][H][W] (or uint8 [B][T][H][W][3]) -> (normalised channels-last 16-bit input of `first_conv`, (T,H,W), B):
+    eight channels per pixel (three real), or four where the first convolution runs over pixel pairs (stem_pairs)."""
     mean, std = VIDEO_STATS[norm_kind]
     if x.dtype == torch.uint8:               # padded decoder frames (B,T,H,W,3) from data.collate_device
         B, T, Hh, W, _ = x.shape
-        cur = L.empty((B * T * Hh * W, 8), act16(), x)
-        H.video_normalize_u8_ndhwc(x, cur, mean, std)
     else:
         B, _, T, Hh, W = x.shape
-        cur = L.empty((B * T * Hh * W, 8), act16(), x)
+    cpp = 4 if (first_conv is not None and stem_pairs(first_conv, (T, Hh, W))) else 8
+    cur = L.empty((B * T * Hh * W, cpp), act16(), x)
+    if x.dtype == torch.uint8:
+        H.video_normalize_u8_ndhwc(x, cur, mean, std)
+    else:
         H.video_normalize_ndhwc(x, cur, mean, std)
-    return run_plan(net.units(), cur, (T, Hh, W), B, training, save, first=True)
+    return cur, (T, Hh, W), B
+
+
+def trunk_forward(net, x, norm_kind, training, save):
+    """x fp32 [B][3][T][H][W] (or uint8 [B][T][H][W][3]) -> (z 16-bit [B*T'*H'*W'][512], (T',H',W'), tape)."""
+    plan = net.units()
+    cur, (T, Hh, W), B = normalized_input(x, norm_kind, plan[0][1] if plan and plan[0][0] == "unit" else None)
+    return run_plan(plan, cur, (T, Hh, W), B, training, save, first=True)
 
 
 FUSE_BN_APPLY = True   # A/B switch (tools/ab_step.py fuse_bn_apply): see run_plan

@@ -178,9 +178,7 @@ def _report(batch, frames, size, samples, version, bwd, autocast, blocks, thread
     # HIP, stage by stage (free running)
     with torch.no_grad():
         x = gb.video
-        cur = torch.empty(x.numel() // 3, 8, dtype=H.act16(), device="cuda")
-        H.video_normalize_ndhwc(x, cur, *PV.VIDEO_STATS["peppa"])
-        thw = tuple(x.shape[2:])
+        cur, thw, _ = PV.normalized_input(x, "peppa", hv.stem_plan()[0][1])
         cur, thw, _ = PV.run_plan(hv.stem_plan(), cur, thw, B, True, False, first=True)
         log(f"{'stage':8s} {'HIP rel-L2':>12s} {'torch-bf16':>12s}")
         res["stages"] = {}

@@ -1298,3 +1298,49 @@ def test_fused_batchnorm_apply_matches_the_separate_pass(case):
     xo = torch.randn(other.Min, other.in_cstride, device=DEV).to(torch.bfloat16)
     with pytest.raises(Exception):
         L.conv_fwd(xo, other, wo, x_bn=(torch.ones(other.in_cstride, device=DEV), torch.zeros(other.in_cstride, device=DEV), True))
+
+
+@pytest.mark.parametrize("case", [
+    # Co, k, s, p, B, T, H, W   -- first convolutions over three input channels with stride 2 along W
+    (45, (1, 7, 7), (1, 2, 2), (0, 3, 3), 2, 3, 20, 24),      # r2plus1d_18's stem
+    (64, (3, 7, 7), (1, 2, 2), (1, 3, 3), 1, 4, 12, 16),      # r3d_18 / mc3_18
+    (64, (1, 7, 7), (1, 2, 2), (0, 3, 3), 3, 1, 16, 18),      # resnet18 (frames as a batch of images)
+    (16, (1, 3, 3), (1, 2, 2), (0, 1, 1), 1, 2, 9, 10),       # even padding: two pair taps
+])
+def test_paired_pixel_stem_matches_conv3d(case):
+    """The first convolution over an input stored with four channels per pixel, run as a stride-1 convolution over pixel
+    pairs (ConvGeom.paired_stem, pp_video_normalize_ndhwc4, pp_prep_conv_weight_pairs / pp_unprep_conv_grad_pairs): forward
+    and weight gradient against torch's conv3d on the same bf16-rounded operands, and bit-identical to the 8-channel route."""
+    Co, k, s, p, B, T, Hh, W = case
+    g = torch.Generator().manual_seed(Co + W)
+    x = torch.rand(B, 3, T, Hh, W, generator=g)
+    w = (torch.randn(Co, 3, *k, generator=g) / math.sqrt(3 * k[0] * k[1] * k[2]))
+    mean, std = (0.3, 0.4, 0.5), (0.2, 0.25, 0.3)
+    geom = L.ConvGeom.paired_stem(B, (T, Hh, W), 3, Co, k, s, p)
+    plain = L.ConvGeom(B, (T, Hh, W), 3, Co, k, s, p, in_cstride=8, cg_in=8)
+    assert geom is not None and geom.out_thw == plain.out_thw and geom.Kf < plain.Kf
+    x4 = torch.empty(B * T * Hh * W, 4, dtype=torch.bfloat16, device=DEV)
+    x8 = torch.empty(B * T * Hh * W, 8, dtype=torch.bfloat16, device=DEV)
+    H.video_normalize_ndhwc(x.to(DEV), x4, mean, std)
+    H.video_normalize_ndhwc(x.to(DEV), x8, mean, std)
+    assert torch.equal(x4[:, :3], x8[:, :3]) and (x4[:, 3] == 0).all()
+    wf, _ = L.prep_conv_weights(w.to(DEV), geom, need_dgrad=False)
+    wf8, _ = L.prep_conv_weights(w.to(DEV), plain, need_dgrad=False)
+    y, st = L.conv_fwd(x4, geom, wf, stats=True)
+    y8, st8 = L.conv_fwd(x8, plain, wf8, stats=True)
+    dyf = rb(torch.randn(B, Co, *geom.out_thw, generator=g))
+    dy = to_cl(dyf, geom.out_cstride)
+    dw = L.conv_wgrad(x4, dy, geom, tuple(w.shape))
+    dw8 = L.conv_wgrad(x8, dy, plain, tuple(w.shape))
+    torch.cuda.synchronize()
+    # same products in a different order of summation (K is walked pair by pair): bf16 outputs one rounding step apart at most
+    scale = y8.float().abs().max().item()
+    assert (y.float() - y8.float()).abs().max().item() <= 2.0 ** -7 * scale
+    xn = x8[:, :3].float().cpu().view(B, T, Hh, W, 3).permute(0, 4, 1, 2, 3)
+    wr = rb(w).requires_grad_(True)
+    ref = F.conv3d(xn, wr, stride=s, padding=p)
+    close(from_cl(y, B, geom.out_thw, Co), ref, name="paired stem forward vs conv3d")
+    ref.backward(dyf)
+    close(dw, wr.grad, name="paired stem weight gradient vs conv3d")
+    sc = dw8.abs().max().item()
+    assert (dw - dw8).abs().max().item() <= 2e-5 * sc + 1e-6

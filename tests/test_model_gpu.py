@@ -146,10 +146,8 @@ def test_video_stem_teacher_forced():
     out.backward(dout)
     with torch.no_grad():
         xg = batch.video.to(DEV)
-        cur = torch.empty(xg.numel() // 3, 8, dtype=torch.bfloat16, device=DEV)
-        from peppa_amd import hip as H
-        H.video_normalize_ndhwc(xg, cur, *PV.VIDEO_STATS["peppa"])
-        z, thw, tape = PV.run_plan(hv.stem_plan(), cur, tuple(batch.video.shape[2:]), 2, True, True, first=True)
+        cur, thw_in, _ = PV.normalized_input(xg, "peppa", hv.stem_plan()[0][1])
+        z, thw, tape = PV.run_plan(hv.stem_plan(), cur, thw_in, 2, True, True, first=True)
         grads = {}
         PV.trunk_backward(tape, to_cl(dout, 64), grads)
     torch.cuda.synchronize()

@@ -57,6 +57,8 @@ def set_switch(name, on):
         from peppa_amd import hip as H
         H.set_option("bn_nt", 2 if on else 0)
         H.set_option("bn_grid", 32768 if on else 4096)
+    elif name == "paired_stem":
+        PV.PAIRED_STEM = on
     elif name == "fuse_bn_apply":
         PV.FUSE_BN_APPLY = on
     elif name.startswith("persist_cus"):       # persist_cus224: the persistent conv / GEMM kernels leave 32 CUs to the other stream
@@ -66,7 +68,7 @@ def set_switch(name, on):
         raise SystemExit(f"unknown switch {name}")
 
 
-defaults = {"fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
+defaults = {"paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
 for _ in range(3):
     step(0)
 for name in sys.argv[1:]:
