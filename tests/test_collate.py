@@ -147,6 +147,12 @@ def test_uint8_stem_input_is_bit_identical_to_the_fp32_route(Hh, W):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
         want = O.normalize_ndhwc_bf16(f32.cpu().numpy(), mean, std).reshape(-1, 8)
         assert np.array_equal(b.view(torch.int16).cpu().numpy().view(np.uint16), want)
+        # four channels per pixel (the paired-pixel stem's input): the same three values and a zero, from either route
+        a4 = torch.empty(f32.numel() // 3, 4, dtype=torch.bfloat16, device="cuda")
+        b4 = torch.empty_like(a4)
+        H.video_normalize_ndhwc(f32, a4, mean, std)
+        H.video_normalize_u8_ndhwc(u8, b4, mean, std)
+        assert torch.equal(a4.view(torch.int16), b4.view(torch.int16)) and torch.equal(a4, a[:, :4])
     with pytest.raises(H.PeppaHipError):
         H.video_normalize_u8_ndhwc(u8.permute(0, 4, 1, 2, 3), b, mean, std)
 
