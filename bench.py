@@ -97,21 +97,33 @@ def cpu_baseline(cfg, args):
 
 def main():
     args = parse()
+    share_gpu = os.environ.get("PEPPA_BENCH_SHARE_GPU") == "1"     # one-GPU rehearsal of the N-rank path (gloo, all ranks on cuda:0)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # called without a launcher: start the ranks ourselves, as CHILD processes, before this process touches the GPU
+        # (never a re-exec), and leave with the launcher's exit code.  Fewer visible GPUs than ranks -> refuse.
+        from peppa_amd.launch import require_devices, spawn_ranks
+        require_devices(args.gpus)
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the record's n_gpus would be wrong")
+    if not share_gpu and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("PEPPA_FORCE_DIST") == "1"
+    backend = "gloo" if share_gpu and world > 1 else "nccl"
     if use_dist:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl")   # (no device_id: the eager communicator made every kernel of the step ~10 % slower)
+        dist.init_process_group(backend)   # (no device_id: the eager communicator made every kernel of the step ~10 % slower)
 
     import yaml
     import pig.models
@@ -249,7 +261,9 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{cfg_name} training step, {args.frames}x{args.size}x{args.size} video + "
                                f"{args.samples / 16000:.1f} s@16kHz audio, batch {args.batch}/GPU{which}",
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                   "global_batch": world * args.batch,
+                   "parallelism": f"dp{world}" + ("+rccl" if use_dist and world == 1 else "")
+                                  + (" (gloo, ranks share cuda:0: rehearsal of the launch path, not a scaling number)" if share_gpu and world > 1 else ""),
                    "gflop_per_pair": round(flops_pair / 1e9, 1),
                    "step_tflops": round(flops_pair * world * args.batch / (ms * 1e-3) / 1e12, 1),
                    "loss": round(float(loss.item()), 5),

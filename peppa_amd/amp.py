@@ -42,6 +42,12 @@ class GradScaler:
         self._reconcile()
         return self._skipped
 
+    def flush(self):
+        """Settle the bookkeeping of the last optimizer step NOW (one event wait): after it `optimizer.state[p]['step']`
+        is what the reference's skipped-step semantics give, also when the very last step of a run overflowed.  The
+        trainer calls it when fit() ends or stops on a limit; checkpoint.optimizer_state calls it for a known scaler."""
+        self._reconcile()
+
     def _reconcile(self, optimizer=None):
         """Wait for the previous step's found-inf flag (recorded long ago) and, if that step was skipped on the device,
         take back the step-counter increment BertAdam made for it."""

@@ -171,9 +171,12 @@ def _plain(obj):
     return obj
 
 
-def optimizer_state(optimizer):
+def optimizer_state(optimizer, scaler=None):
     """BertAdam keeps the reference's per-parameter `step` / `next_m` / `next_v` state (pig/optimization.py:120-128),
-    so the plain `state_dict()` is already what Lightning stores under `optimizer_states`."""
+    so the plain `state_dict()` is already what Lightning stores under `optimizer_states`.  `scaler`: the fp16 run's
+    GradScaler -- flushed first, so a step it skipped on the device does not stay counted in `step`."""
+    if scaler is not None:
+        scaler.flush()
     sd = optimizer.state_dict()
     # state_dict() hands out the optimizer's LIVE per-parameter dicts: build new ones, never move those in place
     state = {key: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
@@ -190,7 +193,7 @@ def save_checkpoint(path, net, optimizer=None, epoch=0, global_step=0, callback_
         "epoch": int(epoch), "global_step": int(global_step), "pytorch-lightning_version": LIGHTNING_VERSION,
         "state_dict": {k: v.detach().cpu() for k, v in net.state_dict().items()},
         "callbacks": {} if callback_state is None else {_callback_key(): dict(callback_state)},
-        "optimizer_states": [] if optimizer is None else [optimizer_state(optimizer)],
+        "optimizer_states": [] if optimizer is None else [optimizer_state(optimizer, scaler)],
         "lr_schedulers": [],
         "hparams_name": "config",
         "hyper_parameters": _plain({k: v for k, v in net.config.items()}),

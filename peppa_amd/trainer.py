@@ -1,8 +1,9 @@
-"""Minimal stand-in for the subset of `pytorch_lightning.Trainer` that run.py uses
-(run.py:56-62 of the reference): fit(), accumulate_grad_batches, limit_train_batches, max_time,
-per-step logging.  Used when Lightning is not installed; with Lightning present run.py hands the
-same module to the real Trainer.  One process per GPU; under torch.distributed the gradients go
-through peppa_amd.dist.GradBuckets (RCCL all-reduce, SUM)."""
+"""The subset of `pytorch_lightning.Trainer` that the reference's run.py uses (run.py:56-62): fit(),
+accumulate_grad_batches, limit_train_batches / limit_val_batches, max_steps, max_time, precision, the
+ModelCheckpoint callbacks, resume_from_checkpoint, per-step logging.  run.py ALWAYS uses this loop
+(Lightning is not installed here and the HIP towers own their streams / loss scaling); `pl.Trainer` flags
+outside this subset are reported by run.py and dropped.  One process per GPU; under torch.distributed the
+gradients go through peppa_amd.dist.GradBuckets (RCCL all-reduce, SUM)."""
 import time
 import logging
 import torch
@@ -44,6 +45,7 @@ class Trainer:
         # precision: None / 16 / "bf16" -> the model's own setting (bf16 unless `mi355x: {dtype: fp16}`);
         # "fp16" -> IEEE half like the reference's AMP runs, with dynamic loss scaling (peppa_amd.amp.GradScaler)
         self.precision = None if precision in (None, 16, "16") else str(precision)
+        self._precision_arg = precision
         self.scaler = None
         self.accumulate = max(1, int(accumulate_grad_batches))
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
@@ -92,6 +94,11 @@ class Trainer:
         if getattr(net, "precision", "bf16") == "fp16":
             from .amp import GradScaler
             self.scaler = GradScaler()
+        elif self._precision_arg in (16, "16"):
+            # the reference's `precision: 16` (hparams_base.yaml:45) is fp16 native AMP + GradScaler; here 16 keeps the
+            # model's own 16-bit type.  Say so once, loudly: nobody should find out from a diverging loss curve.
+            log.warning("precision 16 -> %s operands, no loss scaler; pass precision='fp16' (run.py --precision fp16, or "
+                        "`mi355x: {dtype: fp16}`) for the reference's fp16 AMP semantics", getattr(net, "precision", "bf16"))
         buckets = None
         if is_dist():
             buckets = default_buckets(net, next(net.parameters()).device)
@@ -108,15 +115,24 @@ class Trainer:
         t0 = time.time()
         optim.zero_grad(set_to_none=True)
         for epoch in range(first_epoch, self.max_epochs):
+            if self.max_steps is not None and self.global_step >= self.max_steps:
+                break       # e.g. resumed from a checkpoint that had already reached max_steps: not one step more
             self.current_epoch = epoch
-            if self._train_epoch(net, data, optim, buckets, t0):
-                break
+            limit_hit = self._train_epoch(net, data, optim, buckets, t0)
+            if self.scaler is not None:
+                self.scaler.flush()     # a device-skipped last step must not stay counted in BertAdam's `step`
+            # also when a step / time limit ended the epoch early: validate and let the callbacks write (at least)
+            # last.ckpt, so a `--max_steps N` run shorter than an epoch still leaves a checkpoint behind
             if hasattr(data, "val_dataloader") and self.callbacks:
                 metrics = self.validate(net, data)
                 rank0 = not is_dist() or torch.distributed.get_rank() == 0
                 for cb in self.callbacks:
                     if rank0:
                         cb.on_validation_end(net, optim, epoch, self.global_step, metrics, scaler=self.scaler)
+            if limit_hit:
+                break
+        if self.scaler is not None:
+            self.scaler.flush()
         return net
 
     def _restore(self, net, optim, path):
@@ -130,6 +146,10 @@ class Trainer:
         self.global_step = int(cp.get("global_step", 0))
         if self.scaler is not None and cp.get("native_amp_scaling_state"):
             self.scaler.load_state_dict(cp["native_amp_scaling_state"])
+        elif cp.get("native_amp_scaling_state"):
+            log.warning("%s carries an fp16 loss-scaler state (native_amp_scaling_state) but this run has no scaler "
+                        "(precision %s): the state is dropped; resume with precision='fp16' to keep it", path,
+                        getattr(net, "precision", "bf16"))
         for state in callback_states(cp):
             for cb in self.callbacks:
                 if getattr(cb, "monitor", None) == state.get("monitor"):

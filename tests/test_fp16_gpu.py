@@ -174,6 +174,33 @@ def test_grad_scaler_with_bertadam_skips_on_the_device_and_keeps_the_step_counte
     assert [opt.state[p]["step"] for p in params] == [4, 4, 4]
 
 
+def test_overflow_on_the_final_step_is_settled_by_flush():
+    """the step-counter correction of a device-skipped step used to wait for the NEXT scaler call; a run whose
+    last step overflowed kept `step` one too high (warm-up schedule off by one on resume).  flush() / a checkpoint of the
+    optimizer state with the scaler settle it."""
+    import pig.optimization
+    from peppa_amd.checkpoint import optimizer_state
+    g = torch.Generator().manual_seed(5)
+    params = [torch.nn.Parameter(torch.randn(40, 30, generator=g).to(DEV)), torch.nn.Parameter(torch.randn(7, generator=g).to(DEV))]
+    for use_checkpoint in (False, True):
+        opt = pig.optimization.BertAdam(params, lr=1e-2, warmup=0.3, t_total=10)
+        sc = GradScaler(init_scale=128.0)
+        for step in range(3):
+            for p in params:
+                p.grad = (torch.randn(p.shape, generator=g) * sc.get_scale()).to(DEV)
+            if step == 2:
+                params[0].grad[3, 3] = float("nan")          # the LAST step overflows
+            sc.step(opt)
+            sc.update()
+        assert [opt.state[p]["step"] for p in params] == [3, 3]      # not settled yet: the flag is still in flight
+        if use_checkpoint:
+            state = optimizer_state(opt, sc)
+            assert sorted(st["step"] for st in state["state"].values()) == [2, 2]
+        else:
+            sc.flush()
+        assert [opt.state[p]["step"] for p in params] == [2, 2] and sc.skipped_steps == 1
+
+
 def test_fp16_training_steps_with_loss_scaling():
     """A few optimizer steps of the whole model in fp16 under the built-in Trainer (precision="fp16"): BertAdam steps on
     unscaled gradients, nothing overflows into the weights, the loss stays finite and equals the bf16 run's within noise."""

@@ -97,6 +97,39 @@ def test_resume_continues_where_the_checkpoint_stopped(tmp_path):
 
 
 @pytest.mark.gpu
+def test_a_step_limit_inside_an_epoch_still_writes_last_ckpt_and_a_finished_run_does_not_step_again(tmp_path, caplog):
+    """`--max_steps N` shorter than an epoch wrote no checkpoint at all, and resuming a checkpoint that had
+    reached max_steps took one more optimizer step.  Also: `precision: 16` announces that it means bf16 here."""
+    import logging
+    import pig.models
+    from pig.execution import default_config
+    from peppa_amd.checkpoint import ModelCheckpoint, load_checkpoint
+    from peppa_amd.trainer import SyntheticPigData, Trainer
+    cfg = copy.deepcopy(default_config)
+    cfg["video"]["pretrained"] = cfg["audio"]["pretrained"] = False
+    cfg["data"]["train"]["batch_size"] = 26
+    data = SyntheticPigData(cfg["data"], frames=4, size=32, samples=8000, steps_per_epoch=5, val_batches=4)
+    root = str(tmp_path / "run")
+    torch.manual_seed(0)
+    net = pig.models.PeppaPig(cfg).cuda()
+    cb = ModelCheckpoint(monitor="valnarr_triplet", mode="max", save_last=True)
+    with caplog.at_level(logging.WARNING, logger="peppa_amd.trainer"):
+        tr = Trainer(max_epochs=3, max_steps=2, callbacks=[cb], default_root_dir=root, precision=16)
+        tr.fit(net, data)
+    assert tr.global_step == 2 and tr.current_epoch == 0
+    assert any("precision 16 -> bf16" in r.getMessage() for r in caplog.records)
+    last = os.path.join(root, "checkpoints", "last.ckpt")
+    assert load_checkpoint(last)["global_step"] == 2
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    tr2 = Trainer(max_epochs=3, max_steps=2, callbacks=[ModelCheckpoint(monitor="valnarr_triplet", mode="max")],
+                  default_root_dir=root, resume_from_checkpoint=last)
+    tr2.fit(net, data)
+    assert tr2.global_step == 2                       # nothing left to do
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k
+
+
+@pytest.mark.gpu
 def test_weight_operands_are_cached_between_optimizer_steps_and_never_stale():
     """layers.cached_operands: with gradient accumulation (hparams_base.yaml:42 accumulates 8 micro-batches) and in
     validation the 16-bit operand layouts are built once per optimizer step, not once per forward pass; they must be
