@@ -90,6 +90,8 @@ PROFILE_MIN_FLOP = 1.5e11   # only the big launches are timed: every timed launc
 _MODE_NAMES = {DENSE: "dense", CONV_FWD: "conv_fwd", CONV_DGRAD: "conv_dgrad"}
 
 
+LAUNCH_LOG = None      # a list -> every pp_igemm / pp_wgrad call appends (entry, mode, M, N, K, nbatch, taps, strides, cg): ONE
+                       # kernel launch each, in host order = rocprofv3's Dispatch_Id order (tools/prof_shapes.py joins them)
 PROFILE_STREAM = None  # only launches on this stream are timed (the video trunk's stream in bench.py)
 PROFILE_ONLY = None    # if set: only this kernel family is timed (bench.py picks it during warm-up)
 
@@ -168,6 +170,8 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
         d.bnr_y, d.bnr_z = _p(y, act16()), _p(z, act16())
         d.bnr_mean, d.bnr_rstd, d.bnr_scale, d.bnr_shift = _p(mean, f32), _p(rstd, f32), _p(scale, f32), _p(shift, f32)
         d.bnr_relu, d.bnr_partials = int(relu), _p(partials, f32)
+    if LAUNCH_LOG is not None:
+        LAUNCH_LOG.append(("igemm", _MODE_NAMES[g.mode], M, N, K, nbatch, (g.kt, g.kh, g.kw), (g.st, g.sh, g.sw), g.cg))
     rc = []
     _profiled(f"{_igemm_family(g)}<{_MODE_NAMES[g.mode]}> N={N} K={K}", 2.0 * M * N * K * nbatch,
               lambda: rc.append(call("pp_igemm", C.byref(d), _s())))
@@ -196,6 +200,8 @@ def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=
     d.X, d.dY, d.ldy, d.dW, d.ldw = _p(X, act16()), _p(dY, act16()), ldy, _p(dW, f32), ldw
     d.msplit, d.nbatch, d.x_s, d.dy_s, d.dw_s = msplit, nbatch, x_s, dy_s, dw_s
     d.dbias, d.dbias_s = _p(dbias, f32), dbias_s
+    if LAUNCH_LOG is not None:
+        LAUNCH_LOG.append(("wgrad", _MODE_NAMES[g.mode], M, Ni, Kj, nbatch, (g.kt, g.kh, g.kw), (g.st, g.sh, g.sw), g.cg))
     _profiled(f"{_wgrad_family(g)}<{_MODE_NAMES[g.mode]}> Ni={Ni} Kj={Kj}", 2.0 * M * Ni * Kj * nbatch,
               lambda: call("pp_wgrad", C.byref(d), _s()))
 

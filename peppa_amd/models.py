@@ -207,28 +207,37 @@ def _load_weights_file(path):
 
 
 def _load_fairseq_checkpoint(path, weights=None):
-    """pig/models.py:70-72 imports the fairseq checkpoint `path` through fairseq + torchaudio's import_fairseq_model;
-    neither package exists offline.  `weights` (yaml: `mi355x: {audio_weights: file}`) is the same model already
-    converted: a state_dict with torchaudio parameter names (what `import_fairseq_model(...).state_dict()` saves)."""
-    if weights is None:
-        raise RuntimeError(f"audio.pretrained=true needs the fairseq checkpoint {path!r} and fairseq itself "
-                           "(pig/models.py:70-72); neither is available offline. Use pretrained: false (run.py "
-                           "--random_init), or give `mi355x: {audio_weights: <state_dict with torchaudio names>}`.")
+    """pig/models.py:70-72: `load_model_ensemble_and_task([path])` + torchaudio's `import_fairseq_model(model, num_out=28)`.
+    Neither fairseq nor torchaudio exists here; what the two calls do to the numbers is a renaming of the checkpoint's
+    state dict (pre-training heads dropped, the 28-way readout left freshly initialised), which peppa_amd.convert does
+    on the file itself.  `weights` (yaml: `mi355x: {audio_weights: file}`) is the alternative: the same model already
+    converted, a state_dict with torchaudio parameter names (what `import_fairseq_model(...).state_dict()` saves)."""
+    import os
     audio = A.wav2vec2_base(num_out=28)
-    audio.load_state_dict(_load_weights_file(weights))
-    return audio
+    if weights is not None:
+        audio.load_state_dict(_load_weights_file(weights))
+        return audio
+    if path is not None and os.path.isfile(path):
+        from .convert import load_fairseq_wav2vec2
+        load_fairseq_wav2vec2(path, audio)
+        return audio
+    raise RuntimeError(f"audio.pretrained=true needs the fairseq checkpoint {path!r} (pig/models.py:70-72, README.md:13: a "
+                       "download), which is not there. Put the file in place, use pretrained: false (run.py "
+                       "--random_init), or give `mi355x: {audio_weights: <state_dict with torchaudio names>}`.")
 
 
 def _pretrained_trunk(trunk, kind, weights):
     """`pretrained=True` downloads Kinetics / ImageNet weights in the reference (pig/models.py:123-127,164).  Offline
     that is impossible, and silently training from random init while the config (and every checkpoint's
     hyper_parameters) says `pretrained: true` is worse than failing: require the weights as a local state_dict with
-    torchvision parameter names (yaml: `mi355x: {video_weights: file}`)."""
+    torchvision parameter names (yaml: `mi355x: {video_weights: file}`) -- the file torchvision itself would have
+    downloaded loads as it is (peppa_amd.convert.video_state_dict checks names and shapes)."""
     if weights is None:
         raise RuntimeError(f"video.pretrained=true needs the {kind} weights torchvision would download; they cannot be "
                            "fetched offline. Use pretrained: false (run.py --random_init), or give "
                            "`mi355x: {video_weights: <state_dict with torchvision names>}`.")
-    trunk.load_state_dict(_load_weights_file(weights))
+    from .convert import video_state_dict
+    trunk.load_state_dict(video_state_dict(_load_weights_file(weights), trunk))
     return trunk
 
 

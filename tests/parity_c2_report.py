@@ -117,22 +117,35 @@ def blocks_teacher_forced(rv, hv, x0, B, log=print):
 
 
 def report(batch=8, frames=16, size=112, samples=36800, version="r2plus1d_18", bwd=True, autocast=True, blocks=True,
-           threads=16, log=print, precision="bf16"):
-    """precision: "bf16" | "fp16" -- which build of the HIP library runs (the yardstick stays torch's bf16 autocast)."""
+           threads=16, log=print, precision="bf16", cfg=None, pair=None, data=None, hinge=False):
+    """precision: "bf16" | "fp16" -- which build of the HIP library runs (the yardstick stays torch's bf16 autocast).
+    cfg / pair / data: a prepared config, (oracle, HIP model) pair with equal weights, and ClipBatch (defaults: the
+    default config at `version`, a fresh random-init pair, iid-noise clips).  hinge: differentiate the triplet loss itself
+    instead of the smooth objective (meaningful once the embeddings are separated, i.e. for a trained model)."""
     prev = H.set_precision(precision)
     try:
-        return _report(batch, frames, size, samples, version, bwd, autocast, blocks, threads, log, precision)
+        return _report(batch, frames, size, samples, version, bwd, autocast, blocks, threads, log, precision, cfg, pair,
+                       data, hinge)
     finally:
         H.set_precision(prev)
 
 
-def _report(batch, frames, size, samples, version, bwd, autocast, blocks, threads, log, precision):
+def _gkey(n):
+    parts = n.split(".")
+    if parts[0] == "video_encoder" and parts[1] == "video":
+        return ".".join(parts[:3])
+    return ".".join(parts[:2]) if parts[0] == "video_encoder" else "audio"
+
+
+def _report(batch, frames, size, samples, version, bwd, autocast, blocks, threads, log, precision, cfg=None, pair=None,
+            data=None, hinge=False):
     torch.set_num_threads(threads)
-    cfg = make_cfg(version)
-    ref, net = build_pair(cfg)
+    cfg = make_cfg(version) if cfg is None else cfg
+    ref, net = build_pair(cfg) if pair is None else pair
     net.set_precision(precision)
-    data = synthetic_batch(batch, frames, size, samples)
-    B = batch
+    data = synthetic_batch(batch, frames, size, samples) if data is None else data
+    B = batch = data.video.shape[0]
+    ref.zero_grad(set_to_none=True)       # (a prepared pair may come from an earlier report)
     rv, hv = ref.video_encoder.video, net.video_encoder.video
     acts = {}
     hooks = [getattr(rv, s).register_forward_hook(lambda m, i, o, s=s: acts.__setitem__(s, o.detach())) for s in STAGES]
@@ -158,13 +171,18 @@ def _report(batch, frames, size, samples, version, bwd, autocast, blocks, thread
         V16 = V16g.detach().float()
         acts16 = dict(acts)
         if bwd:
-            (V16g.float() * Rv).sum().backward()
+            if hinge:
+                with torch.no_grad():
+                    A16 = ref2.encode_audio(data.audio)
+                ref2.loss(V16g.float(), A16).backward()
+            else:
+                (V16g.float() * Rv).sum().backward()
             grads16 = {n: p.grad for n, p in ref2.named_parameters() if p.grad is not None}
         del ref2
         log(f"oracle bf16-autocast forward+backward {time.time() - t0:.1f} s")
     if bwd:
         t0 = time.time()
-        ((V32 * Rv).sum() + (A32 * Ra).sum()).backward()
+        (loss32 if hinge else (V32 * Rv).sum() + (A32 * Ra).sum()).backward()
         log(f"oracle backward {time.time() - t0:.1f} s")
     ref_grads = {n: p.grad.detach().clone() for n, p in ref.named_parameters() if p.grad is not None}
     for h in hooks:
@@ -198,7 +216,7 @@ def _report(batch, frames, size, samples, version, bwd, autocast, blocks, thread
     hv.load_state_dict(bn_state)
     if bwd:
         Vg, Ag = net.encode_pair(gb.video, gb.audio)
-        ((Vg * Rv.cuda()).sum() + (Ag * Ra.cuda()).sum()).backward()
+        (net.loss(Vg, Ag) if hinge else (Vg * Rv.cuda()).sum() + (Ag * Ra.cuda()).sum()).backward()
     torch.cuda.synchronize()
     hv.load_state_dict(bn_state)
     with torch.no_grad():
@@ -221,24 +239,120 @@ def _report(batch, frames, size, samples, version, bwd, autocast, blocks, thread
         by_stage = {}
         gmax = max(g.norm().item() for g in ref_grads.values())
         for n, p in net.named_parameters():
-            if n not in ref_grads or p.grad is None:
+            if n not in ref_grads:
+                continue
+            if p.grad is None:
+                res.setdefault("missing_grads", []).append(n)     # the oracle has a gradient here, the HIP path none
                 continue
             rg = ref_grads[n]
-            parts = n.split(".")
-            key = ".".join(parts[:3]) if parts[0] == "video_encoder" and parts[1] == "video" else \
-                (".".join(parts[:2]) if parts[0] == "video_encoder" else "audio")
-            d = by_stage.setdefault(key, [0.0, 0.0, 0.0, 0.0])
-            d[0] += (p.grad.detach().cpu() - rg).pow(2).sum().item()
+            hg = p.grad.detach().float().cpu()
+            d = by_stage.setdefault(_gkey(n), [0.0] * 8)
+            d[0] += (hg - rg).pow(2).sum().item()
             d[1] += rg.pow(2).sum().item()
             if rg.norm().item() > 1e-4 * gmax:     # (tensors whose true gradient is ~0, e.g. k_proj.bias: skip)
-                d[2] = max(d[2], rel(p.grad, rg))
+                d[2] = max(d[2], rel(hg, rg))
+            d[4] += (hg * rg).sum().item()
+            d[5] += hg.pow(2).sum().item()
             if grads16 is not None and n in grads16:
-                d[3] += (grads16[n].float() - rg).pow(2).sum().item()
-        log("gradient rel-L2 per stage under <V,Rv> + <A,Ra> (all tensors pooled / worst tensor / torch bf16 autocast pooled):")
-        res["grads"] = {}
-        for k, (e, r, w, e16) in by_stage.items():
-            res["grads"][k] = ((e / (r + 1e-30)) ** 0.5, w, (e16 / (r + 1e-30)) ** 0.5)
-            log(f"  {k:32s} {res['grads'][k][0]:9.4f} {w:9.4f} {res['grads'][k][2]:9.4f}")
+                g16 = grads16[n].float()
+                d[3] += (g16 - rg).pow(2).sum().item()
+                d[6] += (g16 * rg).sum().item()
+                d[7] += g16.pow(2).sum().item()
+        what = "the triplet loss" if hinge else "<V,Rv> + <A,Ra>"
+        log(f"gradients per stage under {what}, all tensors of a stage pooled, against the fp32 oracle:")
+        log(f"  {'stage':32s} {'rel-L2':>8s} {'worst':>8s} {'|g|/|ref|':>9s} {'cosine':>8s}   torch bf16 autocast: "
+            f"{'rel-L2':>8s} {'|g|/|ref|':>9s} {'cosine':>8s}")
+        res["grads"], res["gstats"] = {}, {}
+        for k, (e, r, w, e16, dot, hh, dot16, yy) in by_stage.items():
+            r = r + 1e-30
+            res["grads"][k] = ((e / r) ** 0.5, w, (e16 / r) ** 0.5 if yy else float("nan"))
+            st = dict(ratio=(hh / r) ** 0.5, cos=dot / ((hh * r) ** 0.5 + 1e-30),
+                      ratio16=(yy / r) ** 0.5 if yy else float("nan"),
+                      cos16=dot16 / ((yy * r) ** 0.5 + 1e-30) if yy else float("nan"))
+            res["gstats"][k] = st
+            log(f"  {k:32s} {res['grads'][k][0]:8.4f} {w:8.4f} {st['ratio']:9.4f} {st['cos']:8.4f}   "
+                f"{'':21s}{res['grads'][k][2]:8.4f} {st['ratio16']:9.4f} {st['cos16']:8.4f}")
+        if res.get("missing_grads"):
+            log("  NO gradient on the HIP path for:", res["missing_grads"][:8])
+        extra = [n for n, p in net.named_parameters() if p.grad is not None and n not in ref_grads]
+        res["extra_grads"] = extra
+        if extra:
+            log("  gradient on the HIP path where the oracle has none:", extra[:8])
+    return res
+
+
+def conditioned_report(steps=300, batch=8, frames=16, size=112, samples=36800, lr=2e-4, pool=6, log=print, threads=16):
+    """Full-depth parity for a CONDITIONED model: the HIP model is trained `steps` optimizer steps
+    on structured synthetic clips (BertAdam, the triplet loss, `pool` different batches in rotation), its state --
+    weights AND BatchNorm running statistics -- is loaded into the oracle, and the free-running stage errors, the
+    embeddings, and the full-depth gradients of BOTH the smooth objective and the triplet loss itself are compared on a
+    held-out batch.  Answers whether the ~100 % full-depth gradient error of the random-init trunk is the chaos of
+    random initialisation (then it shrinks here) or the kernels (then it does not)."""
+    import pig.optimization
+    torch.set_num_threads(threads)
+    cfg = make_cfg()
+    ref, net = build_pair(cfg)
+    batches = [synthetic_structured_batch(batch, frames, size, samples, seed=100 + k).to("cuda") for k in range(pool)]
+    optim = pig.optimization.BertAdam(net.parameters(), lr=lr, warmup=0.05, t_total=2 * steps)
+    t0, losses = time.time(), []
+    for i in range(steps):
+        optim.zero_grad(set_to_none=True)
+        loss = net.training_step(batches[i % pool], i)
+        loss.backward()
+        optim.step()
+        if i % max(1, steps // 10) == 0 or i == steps - 1:
+            losses.append(round(loss.item(), 4))
+    torch.cuda.synchronize()
+    log(f"trained the HIP model {steps} steps on structured clips in {time.time() - t0:.1f} s; loss {losses}")
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    held = synthetic_structured_batch(batch, frames, size, samples, seed=999)
+    out = {"train_losses": losses}
+    log("-- smooth objective --")
+    out["smooth"] = report(blocks=False, log=log, cfg=cfg, pair=(ref, net), data=held, threads=threads)
+    log("-- the triplet loss itself --")
+    out["hinge"] = report(blocks=False, log=log, cfg=cfg, pair=(ref, net), data=held, threads=threads, hinge=True)
+    return out
+
+
+def forward_b64(batch=64, frames=16, size=112, samples=36800, log=print, threads=16):
+    """BASELINE configs[1] at its TRUE batch (64 clips): both encoders + loss against the fp32 oracle (forward only:
+    ~15 s of CPU, no graph kept)."""
+    torch.set_num_threads(threads)
+    cfg = make_cfg()
+    ref, net = build_pair(cfg)
+    data = synthetic_batch(batch, frames, size, samples)
+    t0 = time.time()
+    with torch.no_grad():
+        V32 = ref.encode_video(data.video)
+        A32 = ref.encode_audio(data.audio)
+        loss32 = ref.loss(V32, A32).item()
+    log(f"oracle forward at batch {batch}: {time.time() - t0:.1f} s, loss {loss32:.6f}")
+    gb = data.to("cuda")
+    with torch.no_grad():
+        Vh, Ah = net.encode_pair(gb.video, gb.audio)
+        loss = net.loss(Vh, Ah).item()
+    Vh, Ah = Vh.cpu(), Ah.cpu()
+    res = dict(video_cos=F.cosine_similarity(Vh, V32, dim=1).min().item(), video_maxabs=(Vh - V32).abs().max().item(),
+               audio_cos=F.cosine_similarity(Ah, A32, dim=1).min().item(), audio_maxabs=(Ah - A32).abs().max().item(),
+               loss=loss, loss_ref=loss32, dloss=abs(loss - loss32))
+    log(f"batch {batch}: video min cos {res['video_cos']:.6f} max-abs {res['video_maxabs']:.5f}; audio min cos "
+        f"{res['audio_cos']:.6f} max-abs {res['audio_maxabs']:.5f}; loss HIP {loss:.6f} oracle {loss32:.6f}")
+    return res
+
+
+def frozen_report(batch=8, frames=16, size=112, samples=36800, log=print, threads=16):
+    """BASELINE configs[2] (hparams_freeze_wav2vec.yaml: feature extractor + 12 transformer layers frozen,
+    pig/models.py:75-81) at the real clip geometry: the trainable audio parameters sit BEFORE the frozen layers
+    (feature projection, positional conv, the encoder's LayerNorm), so their gradients cross all 12 frozen layers by data
+    gradients only (T = 114 attention backward included).  Smooth objective, against the oracle with the same freezing."""
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "hparams_freeze_wav2vec.yaml")))
+    cfg["video"]["pretrained"] = cfg["audio"]["pretrained"] = False
+    res = report(batch, frames, size, samples, blocks=False, autocast=False, log=log, cfg=cfg, threads=threads)
+    ref, net = build_pair(cfg)
+    res["frozen_names"] = [n for n, p in ref.named_parameters() if not p.requires_grad]
+    res["hip_frozen_names"] = [n for n, p in net.named_parameters() if not p.requires_grad]
     return res
 
 
@@ -326,12 +440,21 @@ def main():
     ap.add_argument("--no-autocast", action="store_true")
     ap.add_argument("--no-blocks", action="store_true")
     ap.add_argument("--triplets", action="store_true")
+    ap.add_argument("--conditioned", type=int, default=0, help="train the HIP model this many steps first")
+    ap.add_argument("--b64", action="store_true")
+    ap.add_argument("--frozen", action="store_true")
     ap.add_argument("--clips", type=int, default=128)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--precision", default="bf16")
     args = ap.parse_args()
     log = lambda *a: print(*a, flush=True)
-    if args.triplets:
+    if args.conditioned:
+        conditioned_report(args.conditioned, args.batch, args.frames, args.size, args.samples, log=log, threads=args.threads)
+    elif args.b64:
+        forward_b64(log=log, threads=args.threads)
+    elif args.frozen:
+        frozen_report(args.batch, args.frames, args.size, args.samples, log=log, threads=args.threads)
+    elif args.triplets:
         triplet_flips(args.clips, frames=args.frames, size=args.size, samples=args.samples, threads=args.threads, log=log)
     else:
         report(args.batch, args.frames, args.size, args.samples, args.version, not args.no_bwd, not args.no_autocast,

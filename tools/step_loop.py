@@ -26,9 +26,12 @@ ap.add_argument("--isolated", action="store_true")
 ap.add_argument("--no-overlap-audio", action="store_true")
 ap.add_argument("--no-overlap-wgrad", action="store_true")
 ap.add_argument("--config", default="hparams_base.yaml")
+ap.add_argument("--launch-log", default=None, help="write every pp_igemm / pp_wgrad call (shape, mode) of the run, in launch "
+                                                   "order, as JSON: tools/prof_shapes.py joins it with the kernel trace")
 args = ap.parse_args()
 
 import pig.models
+from peppa_amd import hip as H
 from peppa_amd import video as PV
 from peppa_amd.data import synthetic_batch
 
@@ -64,6 +67,8 @@ def step(i):
         opt.step()
 
 
+if args.launch_log:
+    H.LAUNCH_LOG = []
 for i in range(args.warmup):
     step(i)
 torch.cuda.synchronize()
@@ -71,6 +76,11 @@ t0 = time.perf_counter()
 for i in range(args.steps):
     step(args.warmup + i)
 torch.cuda.synchronize()
+if args.launch_log:
+    import json
+    with open(args.launch_log, "w") as f:
+        json.dump({"steps": args.steps, "warmup": args.warmup, "batch": args.batch, "frames": args.frames,
+                   "samples": args.samples, "dtype": args.dtype, "isolated": args.isolated, "launches": H.LAUNCH_LOG}, f)
 print(f"{(time.perf_counter() - t0) / args.steps * 1e3:.2f} ms/step over {args.steps} steps ({args.warmup} warm-up), "
       f"isolated={args.isolated}, dtype={args.dtype}, frames={args.frames}, samples={args.samples}, audio overlap "
       f"{net._overlap}, wgrad overlap {PV.OVERLAP_WGRAD}")
