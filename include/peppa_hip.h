@@ -39,6 +39,8 @@ int pp_dtype(void);
  *                      1 also takes shapes the (3,1,1) kernel would decline as not worth it)
  *   "ring_wgrad"   n   LDS-DMA ring variant of the generic weight gradient once M >= n (default 0 = never)
  *   "win_tall"     0/1/2  512-row window tiles for narrow outputs (1: with enough rows, the default; 2: always)
+ *   "win_stagger"  0/1 window kernels with three weight slots: waves 4-7 request their fragments ahead of the K-step's
+ *                      barrier, so that the two halves' LDS reads and MFMAs alternate instead of coinciding
  *   "win_out_nt"   0/1 non-temporal stores of the window kernels' output tiles (default 1)
  *   "bn_nt" b, "bn_grid" n   BatchNorm streaming passes: non-temporal loads (bit 0) / stores (bit 1), workgroups per launch
  *   "persist_cus"  n   workgroups of the persistent ring / window kernels (8..256, default 256 = one per CU) */

@@ -22,6 +22,7 @@ extern int pp_opt_win_temporal;
 extern int pp_opt_win_out_nt;
 extern int pp_opt_persist_cus;
 extern int pp_opt_win_igemm;
+extern int pp_opt_win_stagger;
 
 // Timing ablations for tools/probe/win_ablate.py (results are WRONG with any bit set; the shipped library has 0):
 // 1 weights only for a workgroup's first tile, 2 windows likewise, 4 no fragment reads / MFMAs, 8 no epilogue,
@@ -127,7 +128,8 @@ struct WinArgs {
 // BNR = the epilogue also accumulates the BatchNorm-backward sums (sum g, sum g * xhat) of the layer that consumes this
 // output as its dz: the tile is in registers / LDS anyway, so bn_bwd_reduce's pass over dz (2 B per element of HBM
 // traffic, a launch) disappears; its read of y moves here.
-template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false>
+// STG = staggered halves (spatial form, three weight slots): see the K-step below.
+template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false, bool STG = false>
 __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap, const int out_nt) {
   constexpr int BM = 16 * MT * NW;
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   constexpr int SMEM = NWIN * WIN_BYTES + NBS * B_BYTES + 256 + 64 + (BNA ? 2 * BNA_CH * 4 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static_assert(!BNA || (TW && CC == 48), "BNA: temporal form, 48-channel chunks");
+  static_assert(!STG || (!TW && NBS == 3 && !BNA), "staggered halves: spatial form with a three-slot weight ring");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];   // one LDS object (see igemm.hip)
   unsigned char* const bring = smem + NWIN * WIN_BYTES;
   unsigned char* const zrow = smem + NWIN * WIN_BYTES + NBS * B_BYTES;    // 256 zero bytes
@@ -350,7 +353,15 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   // K-step j of a chunk (j is a compile-time constant after unrolling)
   // `issue_dmas` runs between the fragment requests and the MFMAs: an LDS-DMA instruction takes 100+ cycles to issue, the
   // fragments about as long to arrive
-  auto compute = [&](const int j, const unsigned char* win, const unsigned char* bslot, auto issue_dmas) __attribute__((always_inline)) {
+  // `sync` = this K-step's wait + barrier.  Staggered halves (STG): the eight waves of the lockstep form request their
+  // fragments together (176 KB per K-step: the LDS is busy, the matrix pipes idle), then multiply together (LDS idle) and
+  // meet at the next barrier.  With `early` (waves 4-7 from a phase's second K-step on) a wave requests its fragments
+  // BEFORE the barrier: while it waits there, its SIMD partner (waves w and w + 4 share a SIMD) is still multiplying, and
+  // after the barrier it multiplies while the partner reads -- reads and MFMAs of the two halves alternate instead of
+  // coinciding.  What that needs: the weights of step s + 1 have landed when the barrier of step s opens (the weight waves
+  // wait for ALL their DMAs, not for all but the youngest batch), and a phase's first K-step stays in lockstep (its window
+  // is published by that step's barrier).
+  auto compute = [&](const int j, const unsigned char* win, const unsigned char* bslot, auto issue_dmas, auto sync, const bool early) __attribute__((always_inline)) {
     // every fragment of the K-step is requested before the first MFMA: written as "load one weight fragment, use it"
     // hipcc keeps ONE fragment register and waits lgkmcnt(0) before every MFMA pair, i.e. one exposed LDS round trip
     // (~100 cycles) per 32 cycles of matrix work
@@ -360,10 +371,14 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     constexpr bool REUSE_B = WN >= 8;
     h16x8 af[2][MT], bfm[REUSE_B ? 1 : 2][WN];
     if (ABL & 4) {
+      sync();
       issue_dmas(-1);
       return;
     }
-    issue_dmas(0);
+    if (!early) {
+      sync();
+      issue_dmas(0);
+    }
     const unsigned wbase = (unsigned)(uintptr_t)(lds_ptr)win;
     const unsigned bbase = (unsigned)(uintptr_t)(lds_ptr)bslot + bfr0;
     auto load_a = [&](const int ks) __attribute__((always_inline)) {
@@ -396,6 +411,11 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     if (!REUSE_B) {
 #pragma unroll
       for (int jn = 0; jn < WN; ++jn) bfm[REUSE_B ? 0 : 1][jn] = load_b(1, jn);
+    }
+    if (early) {
+      __builtin_amdgcn_sched_barrier(0);     // (the requests stay in front of the barrier)
+      sync();
+      issue_dmas(0);
     }
     issue_dmas(1);
     if (ABL & 16) {
@@ -702,12 +722,13 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         // weight waves, three slots: everything but the batch of the previous iteration (the weights of step s + 1) must
         // have landed; two slots: that batch IS the weights of this step.  Window waves: this phase's window, issued at
         // the start of the previous phase, must have landed when the phase starts; nothing to wait for inside a phase.
+        auto sync = [&]() __attribute__((always_inline)) {
         if (win_wave) {
           // this phase's window has landed once only the younger one (D = 2) is still in flight; a tile's first phase
           // also waits for the epilogue's stores, which sit between them in the counter
           if (j == 0) wait_vmcnt_dyn((drain || D == 1) ? 0 : last_win);
         } else {
-          wait_vmcnt_dyn((drain || NBS == 2 || RW) ? 0 : last_batch);
+          wait_vmcnt_dyn((drain || NBS == 2 || RW || STG) ? 0 : last_batch);
         }
         drain = false;
         PP_STAMP(0)
@@ -759,6 +780,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
         }
+        };
         PP_STAMP(1)
         auto issue_dmas = [&](const int pos) __attribute__((always_inline)) {
           if (pos >= 0 && pos != (win_wave ? PP_WIN_WPOS : 1)) return;
@@ -789,7 +811,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
           }
         };
         PP_STAMP(2)
-        compute(j, win, bring + (RW ? chunk * NKC + j : bsl) * B_BYTES, issue_dmas);
+        compute(j, win, bring + (RW ? chunk * NKC + j : bsl) * B_BYTES, issue_dmas, sync, STG && win_wave && j > 0);
         PP_STAMP(3)
         bsl = next_slot(bsl);
       }
@@ -885,6 +907,14 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
     } else {
       pp_set_error("pp_igemm: fused BatchNorm apply is built for the temporal window kernel with 48-channel chunks only");
       return PP_ERR_INVALID;
+    }
+  }
+  if constexpr (!TW && NBS == 3) {
+    if (pp_opt_win_stagger) {    // staggered halves (see the kernel's K-step)
+      if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+      else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+      PP_LAUNCH_CHECK();
+      return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
     }
   }
   if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);

@@ -12,8 +12,13 @@ What bf16 activations cost, measured here with torch's own bf16 autocast of the 
   * backward, one block teacher-forced: dx ~10 %, dW ~11 % (ReLU masks of near-zero activations flip for ~0.5-1 % of
     the elements once the activation is rounded to bf16: relative L2 ~ sqrt(fraction)); asserted <= 13 / 15 %;
   * backward, full depth: a random-init train-mode-BatchNorm trunk is chaotic, torch-bf16's own trunk gradients are
-    ~100 % off fp32 (stem 1.04, layer4 0.83); the HIP path must not be worse than that yardstick, and the
-    well-conditioned parts (audio tower, projection) are asserted tightly.
+    ~100 % off fp32 in relative L2 (stem 1.04, layer4 0.83) -- a figure an all-zero gradient also reaches, so the
+    assertion is on quantities a wrong gradient cannot meet: per stage the NORM ratio against the fp32 oracle within
+    0.9-1.1 and the COSINE not below the yardstick's (0.46-0.53) minus 0.05; the well-conditioned parts (audio tower,
+    projection) are asserted tightly;
+  * the same for a CONDITIONED model (300 optimizer steps on structured clips, state loaded into the oracle): the
+    full-depth error leaves the ~1.0 regime (0.07-0.52) and is asserted with 1.2x headroom;
+  * configs[1] at its true batch 64 (forward + loss) and configs[2] (frozen wav2vec2) at the real geometry.
 """
 import pytest
 
@@ -46,16 +51,84 @@ def test_every_block_teacher_forced_at_real_shape(rep):
         assert fwd <= 0.01 and dx <= 0.13 and dw <= 0.15, (name, fwd, dx, dw)
 
 
+def _assert_full_depth_gradients(g, stats, trunk_rel_bound=None, stem_ratio=(0.9, 1.1)):
+    """A stage's gradient (all its tensors pooled) against the fp32 oracle: the NORM ratio within 0.9-1.1 and the COSINE at
+    least the torch-bf16 yardstick's minus 0.05 -- neither a zero, a mis-scaled, a sign-flipped nor a mis-routed gradient
+    can satisfy both (an all-zero gradient has relative L2 error 1.0, which the round-2 form of this test accepted)."""
+    for key, st in stats.items():
+        print(f"  {key:34s} |g|/|ref| {st['ratio']:.4f} cosine {st['cos']:.4f}   (torch bf16: {st['ratio16']:.4f} {st['cos16']:.4f})")
+    for key, st in stats.items():
+        trunk = key.startswith("video_encoder.video.")
+        lo, hi = stem_ratio if key.endswith(".stem") else (0.9, 1.1)
+        assert lo <= st["ratio"] <= hi, (key, st)
+        yard = st["cos16"]
+        floor = yard - 0.05 if yard == yard and yard > 0 else (0.55 if trunk else 0.97)    # (layer4: the yardstick run keeps no fp32 copy)
+        assert st["cos"] >= floor, (key, st, floor)
+        if not trunk:
+            assert st["cos"] >= 0.97, (key, st)
+        if trunk and trunk_rel_bound is not None:
+            assert g[key][0] <= trunk_rel_bound[key.split(".")[-1]], (key, g[key])
+            if g[key][2] == g[key][2]:
+                assert g[key][0] <= 1.15 * g[key][2] + 0.02, (key, g[key])      # never worse than torch's own bf16 run
+
+
 def test_gradients_under_a_smooth_objective(rep):
     g = rep["grads"]
     assert g["audio"][0] <= 0.02 and g["audio"][1] <= 0.06, g["audio"]            # LayerNorm tower: well conditioned
     assert g["video_encoder.project"][0] <= 0.06, g["video_encoder.project"]
-    for key, (ours, worst, yard) in g.items():
-        if key.startswith("video_encoder.video.") or key == "video_encoder.videopool":
-            # chaotic regime (see the module docstring): never worse than torch's own bf16 run of the oracle
-            if yard == yard and yard != float("inf"):
-                assert ours <= 1.1 * yard + 0.02, (key, ours, yard)
-            assert ours <= 1.3, (key, ours)
+    assert not rep.get("missing_grads") and not rep.get("extra_grads"), (rep.get("missing_grads"), rep.get("extra_grads"))
+    # random-init train-mode-BatchNorm trunk: chaotic (module docstring) -- measured r03: |g|/|ref| 0.998-1.018, cosine
+    # 0.465-0.656 against the yardstick's 0.461-0.525
+    _assert_full_depth_gradients(g, rep["gstats"])
+
+
+def test_full_depth_gradients_of_a_conditioned_model():
+    """the HIP model is trained 300 optimizer steps on structured clips, its state is loaded into the
+    oracle and the full-depth comparison is repeated.  Measured (r03, two runs: gpurun_out/r3/par_cond2.log, t1.log; the
+    training itself is not bitwise reproducible, so the trained states differ): the trunk's relative L2 error leaves the
+    ~1.0 regime of random init -- stem 0.49 / 0.60, layer1 0.52 / 0.54, layer2 0.45, layer3 0.27, layer4 0.07, the
+    torch-bf16 yardstick 0.47-0.63 / 0.52-0.55 / 0.45 / 0.27 -- with norm ratios 0.98-1.02 (stem, two conv tensors: 0.87-0.98,
+    the yardstick's 0.94-1.02) and cosines 0.80-0.998; the free-running activations stay within 3.7 % at every stage (25 % at
+    random init).  Asserted with 1.2x headroom on the larger of the two measurements and against the yardstick."""
+    from parity_c2_report import conditioned_report
+    out = conditioned_report(steps=300)
+    assert out["target_cosine"][-1] >= 0.6, out["target_cosine"]        # it did train
+    rep = out["smooth"]
+    assert rep["video_cos"] >= 0.9995 and rep["audio_cos"] >= 0.9995 and rep["dloss"] <= 1e-3
+    for stage, (ours, yard) in rep["stages"].items():
+        assert ours <= 1.05 * yard + 1e-3 and ours <= 0.06, (stage, ours, yard)
+    bound = {"stem": 0.72, "layer1": 0.65, "layer2": 0.55, "layer3": 0.33, "layer4": 0.10}
+    _assert_full_depth_gradients(rep["grads"], rep["gstats"], trunk_rel_bound=bound, stem_ratio=(0.8, 1.2))
+    assert rep["grads"]["audio"][0] <= 0.01 and rep["grads"]["video_encoder.project"][0] <= 0.02
+    if "hinge" in out:      # the triplet loss's own gradient, when its hinges are neither all off nor all on
+        _assert_full_depth_gradients(out["hinge"]["grads"], out["hinge"]["gstats"])
+
+
+def test_configs1_at_its_true_batch_64():
+    """BASELINE configs[1] at batch 64 (not the batch 8 the other tests run): both towers + loss against the fp32 oracle
+    (forward only; the oracle takes ~17 s).  Measured r03: video min cosine 0.999017 / max-abs 7.7e-3, audio 0.999980 /
+    8.8e-4, loss |d| 2.4e-5.  (torch's own bf16 autocast of the oracle sits at 0.9992 at batch 8: the headroom to 0.999 is
+    a property of bf16 operands)"""
+    from parity_c2_report import forward_b64
+    r = forward_b64()
+    assert r["video_cos"] >= 0.999 and r["video_maxabs"] <= 2e-2, r
+    assert r["audio_cos"] >= 0.999 and r["audio_maxabs"] <= 2e-2, r
+    assert r["dloss"] <= 5e-3, r
+
+
+def test_configs2_frozen_wav2vec_at_real_geometry():
+    """BASELINE configs[2] (hparams_freeze_wav2vec.yaml) at 16x112x112 + 36 800 samples, batch 8: the trainable audio
+    parameters sit before the 12 frozen transformer layers (pig/models.py:75-81), so their gradients cross all of them by
+    data gradients alone, T = 114 attention backward included.  Measured r03: audio pooled relative L2 0.6 %, worst tensor
+    1.4 %; exactly the oracle's set of tensors has a gradient."""
+    from parity_c2_report import frozen_report
+    r = frozen_report()
+    assert sorted(r["frozen_names"]) == sorted(r["hip_frozen_names"]) and len(r["frozen_names"]) > 190
+    assert not r.get("missing_grads") and not r.get("extra_grads"), (r.get("missing_grads"), r.get("extra_grads"))
+    assert r["grads"]["audio"][0] <= 0.02 and r["grads"]["audio"][1] <= 0.05, r["grads"]["audio"]
+    st = r["gstats"]["audio"]
+    assert 0.98 <= st["ratio"] <= 1.02 and st["cos"] >= 0.999, st
+    assert r["audio_cos"] >= 0.999 and r["video_cos"] >= 0.999 and r["dloss"] <= 5e-3
 
 
 def test_triplet_accuracy_within_0p2_percent_on_10k_triplets():
