@@ -129,6 +129,12 @@ typedef struct pp_wgrad_desc {
   /* optional: X is the RAW output y of a BatchNorm unit; the kernel uses relu?(y * x_bn_scale + x_bn_shift) (see
    * pp_igemm_desc.a_bn_scale).  Only the temporal sliding-window kernel implements it: pp_wgrad_xbn_supported(d). */
   const float* x_bn_scale; const float* x_bn_shift; int x_bn_relu;
+  /* optional GROUPED launch: `nbatch` independent problems of the same (M, Ni, Kj, gather) whose operands live anywhere:
+   * a device table of nbatch x 4 pointers {X, dY, dW, dbias (or 0)}; X / dY / dW / dbias and the per-batch offsets above
+   * are then ignored (dbias != NULL still says "take the bias gradients").  One launch covers e.g. a weight gradient of all
+   * twelve transformer layers: every (i, j) tile reduces its whole M (msplit = 1), so no sum crosses workgroups and
+   * the result is bitwise reproducible.  Dense gathers with the generic kernel only. */
+  const unsigned long long* ptr_table;
 } pp_wgrad_desc;
 int pp_wgrad(const pp_wgrad_desc* d, pp_stream_t s);
 int pp_wgrad_xbn_supported(const pp_wgrad_desc* d);

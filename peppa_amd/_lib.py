@@ -47,7 +47,8 @@ class WGradDesc(C.Structure):
         ("msplit", C.c_int), ("nbatch", C.c_int),
         ("x_s", C.c_longlong), ("dy_s", C.c_longlong), ("dw_s", C.c_longlong),
         ("dbias", C.c_void_p), ("dbias_s", C.c_longlong),
-        ("x_bn_scale", C.c_void_p), ("x_bn_shift", C.c_void_p), ("x_bn_relu", C.c_int)]
+        ("x_bn_scale", C.c_void_p), ("x_bn_shift", C.c_void_p), ("x_bn_relu", C.c_int),
+        ("ptr_table", C.c_void_p)]
 
 
 class TensorList(C.Structure):

@@ -420,7 +420,39 @@ def _enc_forward(enc, feat, B, T, save, training=False):
     return out, t
 
 
-def _lin_grads(grads, lin, x, dy, M, N, K):
+GROUP_WGRAD = True    # the transformer layers' weight gradients as ONE launch per Linear shape (layers.linear_wgrad_group)
+
+
+class _Deferred:
+    """Weight gradients of the transformer layers, collected during the backward walk and launched as one grouped
+    problem per Linear shape once the walk has left the layers.  They are off the critical path (nothing downstream reads
+    a dW), so deferring costs nothing, and a grouped launch has 12 x the tiles of a per-layer one: every tile reduces
+    its whole M (no split-M atomics; bitwise reproducible).  Each layer's operands stay alive until then (~100 MB per
+    layer at batch 64: irrelevant against 288 GB)."""
+
+    def __init__(self, M):
+        self.M, self.kinds = M, {}
+
+    def add(self, kind, lins, x, dy, N, K):
+        self.kinds.setdefault((kind, N, K), []).append((lins, x, dy))
+
+    def flush(self, grads):
+        for (kind, N, K), entries in self.kinds.items():
+            outs = L.linear_wgrad_group([(x, dy) for _, x, dy in entries], self.M, N, K)
+            for (lins, _, _), (dw, db) in zip(entries, outs):
+                n_each = N // len(lins)
+                for i, lin in enumerate(lins):
+                    if lin.weight.requires_grad:
+                        grads[lin.weight] = dw[i * n_each:(i + 1) * n_each] if len(lins) > 1 else dw
+                    if lin.bias is not None and lin.bias.requires_grad:
+                        grads[lin.bias] = db[i * n_each:(i + 1) * n_each] if len(lins) > 1 else db
+        self.kinds = {}
+
+
+def _lin_grads(grads, lin, x, dy, M, N, K, deferred=None, kind=None):
+    if deferred is not None and lin.weight.requires_grad and lin.bias is not None and lin.bias.requires_grad:
+        deferred.add(kind, (lin,), x, dy, N, K)
+        return
     need_w, need_b = lin.weight.requires_grad, lin.bias is not None and lin.bias.requires_grad
     if need_w or need_b:
         dw, db = L.linear_wgrad(x, dy, M, N, K, want_bias=need_b)
@@ -447,6 +479,7 @@ def _enc_backward(enc, t, dout, grads):
     H.cast_pad_2d(dout, dy, M, n_out, n_out, M, Np)
     _lin_grads(grads, enc.readout, t.x_final, dy, M, n_out, 768)
     dx = L.linear_dgrad(dy, M, t.ro_wt, 768)
+    deferred = _Deferred(M) if GROUP_WGRAD else None
     for r in reversed(t.layers):
         layer = r.layer
         att, ff = layer.attention, layer.feed_forward
@@ -455,32 +488,37 @@ def _enc_backward(enc, t, dout, grads):
         if r.d_ffo[0] > 0:
             dt2 = L.empty(ds2.shape, act16(), ds2)
             H.dropout_bf16(ds2, dt2, *r.d_ffo)
-        _lin_grads(grads, ff.output_dense, r.h, dt2, M, 768, 3072)
+        _lin_grads(grads, ff.output_dense, r.h, dt2, M, 768, 3072, deferred, "ffn2")
         dh = L.linear_dgrad(dt2, M, r.ff2_wt, 3072)
         du = L.empty(dh.shape, act16(), dh)
         if r.d_int[0] > 0:
             H.gelu_bwd_dropout(dh, r.u, du, *r.d_int)      # dropout mask and GELU derivative in one pass
         else:
             H.gelu_bwd(dh, r.u, du)
-        _lin_grads(grads, ff.intermediate_dense, r.xa, du, M, 3072, 768)
+        _lin_grads(grads, ff.intermediate_dense, r.xa, du, M, 3072, 768, deferred, "ffn1")
         dxa = L.linear_dgrad(du, M, r.ff1_wt, 768, residual=ds2)
         ds1 = _ln_bwd(grads, layer.layer_norm, dxa, r.s1, r.lnA)
         dt1 = ds1
         if r.d_out[0] > 0:
             dt1 = L.empty(ds1.shape, act16(), ds1)
             H.dropout_bf16(ds1, dt1, *r.d_out)
-        _lin_grads(grads, att.out_proj, r.ctx, dt1, M, 768, 768)
+        _lin_grads(grads, att.out_proj, r.ctx, dt1, M, 768, 768, deferred, "out")
         dctx = L.linear_dgrad(dt1, M, r.out_wt, 768)
         dqkv = _attention_bwd(dctx, r.qkv, r.ctx, r.P, B, T, Tp, att.scaling, r.d_att)
         # q/k/v projections share one fused weight gradient
+        qkv_lins = (att.q_proj, att.k_proj, att.v_proj)
         need = any(p.requires_grad for p in (att.q_proj.weight, att.k_proj.weight, att.v_proj.weight))
-        if need:
+        if need and deferred is not None and all(l.weight.requires_grad and l.bias.requires_grad for l in qkv_lins):
+            deferred.add("qkv", qkv_lins, r.x_in, dqkv, 2304, 768)
+        elif need:
             dw, db = L.linear_wgrad(r.x_in, dqkv, M, 2304, 768)
             for i, lin in enumerate((att.q_proj, att.k_proj, att.v_proj)):
                 if lin.weight.requires_grad:
                     grads[lin.weight] = dw[i * 768:(i + 1) * 768]
                     grads[lin.bias] = db[i * 768:(i + 1) * 768]
         dx = L.linear_dgrad(dqkv, M, r.qkv_wt, 768, residual=ds1)
+    if deferred is not None:
+        deferred.flush(grads)
     if t.d_tr[0] > 0:
         H.dropout_bf16(dx, dx, *t.d_tr)
     dx1 = _ln_bwd(grads, tr.layer_norm, dx, t.x1, t.ln1)

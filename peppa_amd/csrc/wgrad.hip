@@ -77,6 +77,14 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
   const h16raw* X = (const h16raw*)p.X + z * p.x_s;
   const h16raw* dY = (const h16raw*)p.dY + z * p.dy_s;
   float* __restrict__ dW = p.dW + z * p.dw_s;
+  float* dbias_z = BIAS ? p.dbias + z * p.dbias_s : nullptr;
+  if (p.ptr_table) {      // grouped launch: problem z has its own operands (uniform scalar loads)
+    const unsigned long long* e = p.ptr_table + 4 * z;
+    X = (const h16raw*)e[0];
+    dY = (const h16raw*)e[1];
+    dW = (float*)e[2];
+    dbias_z = BIAS ? (float*)e[3] : nullptr;
+  }
   const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)OOB, 0x00020000);
   const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, (short)0, (int)OOB, 0x00020000);
   const pp_gather& g = p.g;
@@ -256,21 +264,23 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
     if (st + 1 < nsteps) iteration(st + 1, 0, smem + BUF, smem);
   }
   if (BIAS) {
-    // bias gradient: combine the block's row-threads in LDS first, then ONE global atomic per column
-    float* bred = (float*)smem;   // the loop buffers are free after the final barrier
-    for (int i = tid; i < TI; i += 256) bred[i] = 0.f;
-    __syncthreads();
+    // bias gradient: the block's row-threads meet in LDS and are summed IN ROW ORDER (no LDS float atomics: their
+    // order changes from run to run), then ONE global add per column -- with msplit = 1 its only adder
+    float* part = (float*)smem;   // [cid = row * 2 WI + chunk][8]; the loop buffers are free after the final barrier
+    static_assert(NPI * 256 * 8 * 4 <= 2 * BUF, "bias partials fit the loop buffers");
     if (do_bias) {
 #pragma unroll
       for (int it = 0; it < NPI; ++it)
-        if (prow[it] < MS)
 #pragma unroll
-          for (int q = 0; q < 8; ++q) atomicAdd(bred + pch[it] * 8 + q, bsum[BIAS ? it : 0][q]);
+        for (int q = 0; q < 8; ++q) part[(tid + 256 * it) * 8 + q] = bsum[BIAS ? it : 0][q];
     }
     __syncthreads();
     if (do_bias)
-      for (int i = tid; i < TI; i += 256)
-        if (i0 + i < p.Ni) atomicAdd(p.dbias + z * p.dbias_s + i0 + i, bred[i]);
+      for (int i = tid; i < TI; i += 256) {
+        float v = 0.f;
+        for (int r = 0; r < MS; ++r) v += part[(r * 2 * WI + (i >> 3)) * 8 + (i & 7)];
+        if (i0 + i < p.Ni) atomicAdd(dbias_z + i0 + i, v);
+      }
     __syncthreads();
   }
   // Stage the fp32 tile in LDS (row = i, 128 j columns) so that every atomic wave-instruction adds 256
@@ -702,14 +712,16 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
   PP_CHECK_ARG(dp != nullptr, "pp_wgrad: null descriptor");
   pp_wgrad_desc d = *dp;
   PP_CHECK_ARG(d.M > 0 && d.Ni > 0 && d.Kj > 0, "pp_wgrad: bad sizes");
-  PP_CHECK_ARG(d.X && d.dY && d.dW, "pp_wgrad: null operand");
+  PP_CHECK_ARG(d.ptr_table || (d.X && d.dY && d.dW), "pp_wgrad: null operand");
+  PP_CHECK_ARG(!d.ptr_table || (d.g.mode == PP_DENSE && d.nbatch >= 1 && !d.x_bn_scale && !d.x_bn_shift),
+               "pp_wgrad: a pointer table (grouped launch) needs a dense gather, nbatch >= 1 and no fused BatchNorm");
   PP_CHECK_ARG(d.ldy % 8 == 0 && d.ldy >= ((d.Ni + 7) & ~7), "pp_wgrad: ldy=%d too small/unaligned for Ni=%d", d.ldy, d.Ni);
   PP_CHECK_ARG(d.Kj % 8 == 0 && d.ldw >= d.Kj, "pp_wgrad: Kj=%d must be a multiple of 8 and <= ldw", d.Kj);
   PP_CHECK_ARG(d.g.mode == PP_DENSE || d.g.mode == PP_CONV_FWD, "pp_wgrad: gather mode must be dense or conv-fwd");
   PP_CHECK_ARG(d.g.mode == PP_DENSE || (d.g.kt > 0 && d.g.kh > 0 && d.g.kw > 0 && d.g.kt * d.g.kh * d.g.kw <= 256 && d.g.kt < 256 &&
                                         d.g.kh < 256 && d.g.kw < 256), "pp_wgrad: taps %dx%dx%d unsupported (<=256 total)", d.g.kt, d.g.kh, d.g.kw);
   PP_CHECK_ARG(!d.dbias || d.g.mode == PP_DENSE, "pp_wgrad: the fused bias gradient is only built for dense operands");
-  PP_CHECK_ARG(((uintptr_t)d.X & 15) == 0 && ((uintptr_t)d.dY & 15) == 0, "pp_wgrad: operands must be 16-byte aligned");
+  PP_CHECK_ARG(d.ptr_table || (((uintptr_t)d.X & 15) == 0 && ((uintptr_t)d.dY & 15) == 0), "pp_wgrad: operands must be 16-byte aligned");
   if (d.nbatch <= 0) d.nbatch = 1;
   const int rc = pp_validate_gather(d.g, d.Kj, "pp_wgrad");
   if (rc != PP_OK) return rc;
@@ -728,14 +740,14 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
                  "ask pp_wgrad_xbn_supported first");
     return pp_wgrad_tw_try(d, s, pp_opt_sw_wgrad == 1);
   }
-  if (pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad) {   // (1,3,3) stride-1 convs: window along m
+  if (pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad && !d.ptr_table) {   // (1,3,3) stride-1 convs: window along m
     const int rc_sw = pp_wgrad_sw_try(d, s);
     if (rc_sw != 1) return rc_sw;
     const int rc_tw = pp_wgrad_tw_try(d, s, pp_opt_sw_wgrad == 1);                    // (3,1,1) stride-1 convs: window over time
     if (rc_tw != 1) return rc_tw;
   }
   const int n16 = (d.Ni + 15) / 16;
-  if (pp_opt_ring_wgrad && d.nbatch == 1 && n16 > 4 && (long long)d.M >= pp_opt_ring_wgrad) {
+  if (pp_opt_ring_wgrad && d.nbatch == 1 && !d.ptr_table && n16 > 4 && (long long)d.M >= pp_opt_ring_wgrad) {
     // ring tiles: 128 or 144 rows of dW (less padding wins) x 192 or 256 columns (ditto; 192 on ties)
     const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
     const int j6 = ((d.Kj + 191) / 192) * 192, j8 = ((d.Kj + 255) / 256) * 256;

@@ -191,9 +191,16 @@ def wgrad_xbn_supported(M, Ni, Kj, g, ldy):
     return bool(_lib.lib().pp_wgrad_xbn_supported(C.byref(d)))
 
 
-def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0, dbias=None, dbias_s=0, x_bn=None):
-    """x_bn = (scale, shift, relu): X is a BatchNorm unit's raw output y, the kernel uses relu?(y * scale + shift)."""
+def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=0, dw_s=0, dbias=None, dbias_s=0, x_bn=None,
+          ptr_table=None):
+    """x_bn = (scale, shift, relu): X is a BatchNorm unit's raw output y, the kernel uses relu?(y * scale + shift).
+    ptr_table: int64 device tensor [nbatch][4] = {X, dY, dW, dbias or 0} of a grouped launch (pp_wgrad_desc.ptr_table);
+    X / dY / dW / dbias then only say dtype and "bias wanted"."""
     d = WGradDesc()
+    if ptr_table is not None:
+        if ptr_table.dtype != torch.int64 or not ptr_table.is_cuda or ptr_table.numel() != 4 * nbatch:
+            raise PeppaHipError("wgrad: ptr_table must be an int64 device tensor of nbatch x 4 pointers")
+        d.ptr_table = ptr_table.data_ptr()
     if x_bn is not None:
         d.x_bn_scale, d.x_bn_shift, d.x_bn_relu = _p(x_bn[0], f32), _p(x_bn[1], f32), int(x_bn[2])
     d.M, d.Ni, d.Kj, d.g = M, Ni, Kj, g

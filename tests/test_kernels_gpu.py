@@ -225,6 +225,39 @@ def test_linear_fwd_bwd(M, N, K):
     close(y32[:, :N], y_ref - res, rtol=2e-3, atol=2e-3 * y_ref.abs().max().item(), name="linear fp32 out")
 
 
+@pytest.mark.parametrize("M,N,K,n", [(7296, 768, 768, 5), (1000, 768, 3072, 3), (300, 3072, 768, 2), (257, 2304, 768, 4), (70, 28, 768, 3)])
+def test_grouped_linear_wgrad_matches_torch_and_is_bitwise_reproducible(M, N, K, n):
+    """the same Linear shape of several transformer layers as ONE launch (pp_wgrad_desc.ptr_table):
+    operands anywhere in memory, every tile reduces its whole M.  Against torch fp32 on the bf16-rounded operands (as
+    test_linear_fwd_bwd), equal to the per-problem launches within fp32 summation order, and bit-identical between two
+    launches (no sum crosses workgroups; the bias gradient's in-block reduction runs in row order)."""
+    g = torch.Generator().manual_seed(M + N + n)
+    Kp, Np = L.cpad(K), L.cpad(N)
+    items, refs = [], []
+    for i in range(n):
+        x = rb(torch.randn(M, K, generator=g))
+        dy = rb(torch.randn(M, N, generator=g))
+        xp, dyp = torch.zeros(M, Kp), torch.zeros(M, Np)
+        xp[:, :K], dyp[:, :N] = x, dy
+        pad = torch.empty(17 * (i + 1), device=DEV)          # operands at unrelated addresses
+        items.append((xp.to(torch.bfloat16).to(DEV), dyp.to(torch.bfloat16).to(DEV), pad))
+        refs.append((dy.t() @ x, dy.sum(0)))
+    outs = L.linear_wgrad_group([(a, b) for a, b, _ in items], M, N, K)
+    torch.cuda.synchronize()
+    first = [(dw.clone(), db.clone()) for dw, db in outs]
+    for (dw, db), (rw, rbias), (xc, dyc, _) in zip(outs, refs, items):
+        close(dw, rw, name="grouped wgrad")
+        close(db, rbias, name="grouped bias grad")
+        dw1, db1 = L.linear_wgrad(xc, dyc, M, N, K)
+        torch.cuda.synchronize()
+        assert (dw - dw1).abs().max().item() <= 1e-3 * rw.abs().max().item() + 1e-6
+    for rep in range(3):
+        again = L.linear_wgrad_group([(a, b) for a, b, _ in items], M, N, K)
+        torch.cuda.synchronize()
+        for (dw, db), (dw0, db0) in zip(again, first):
+            assert torch.equal(dw, dw0) and torch.equal(db, db0), rep
+
+
 def test_batched_attention_gemms():
     """Q K^T per (batch, head) with strided operands, softmax, and the per-head transpose."""
     g = torch.Generator().manual_seed(4)

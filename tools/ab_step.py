@@ -61,6 +61,12 @@ def set_switch(name, on):
         PV.PAIRED_STEM = on
     elif name == "fuse_bn_apply":
         PV.FUSE_BN_APPLY = on
+    elif name == "group_wgrad":
+        from peppa_amd import audio as PA
+        PA.GROUP_WGRAD = on
+    elif name == "win_stagger":
+        from peppa_amd import hip as H
+        H.set_option("win_stagger", 1 if on else 0)
     elif name.startswith("persist_cus"):       # persist_cus224: the persistent conv / GEMM kernels leave 32 CUs to the other stream
         from peppa_amd import hip as H
         H.set_option("persist_cus", int(name[len("persist_cus"):]) if on else 256)
@@ -68,7 +74,7 @@ def set_switch(name, on):
         raise SystemExit(f"unknown switch {name}")
 
 
-defaults = {"paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
+defaults = {"group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
 for _ in range(3):
     step(0)
 for name in sys.argv[1:]:
