@@ -39,6 +39,12 @@ int pp_dtype(void);
  *                      1 also takes shapes the (3,1,1) kernel would decline as not worth it)
  *   "ring_wgrad"   n   LDS-DMA ring variant of the generic weight gradient once M >= n (default 0 = never)
  *   "win_tall"     0/1/2  512-row window tiles for narrow outputs (1: with enough rows, the default; 2: always)
+ *   "deterministic" 0/1  bitwise-reproducible results: every sum that crosses workgroups is taken in a fixed order instead
+ *                      of by fp32 atomics -- weight gradients through per-split slabs (pp_wgrad_desc.ws) and an ordered
+ *                      pass, the wav2vec2 conv0 statistics / weight-norm sums / column sums by one workgroup per sum,
+ *                      BertAdam's per-tensor norms and the loss over per-block partials, the fp32 head GEMMs without split-K.
+ *                      Default 0: the atomics are faster (cost: DESIGN.md section 7); LayerNorm and BatchNorm reductions
+ *                      are ordered in either mode
  *   "win_stagger"  0/1 window kernels with three weight slots: waves 4-7 request their fragments ahead of the K-step's
  *                      barrier, so that the two halves' LDS reads and MFMAs alternate instead of coinciding
  *   "win_out_nt"   0/1 non-temporal stores of the window kernels' output tiles (default 1)
@@ -135,8 +141,14 @@ typedef struct pp_wgrad_desc {
    * twelve transformer layers: every (i, j) tile reduces its whole M (msplit = 1), so no sum crosses workgroups and
    * the result is bitwise reproducible.  Dense gathers with the generic kernel only. */
   const unsigned long long* ptr_table;
+  /* deterministic mode (pp_set_option("deterministic", 1)): where M is split over workgroups, every split stores its
+   * partial tile to a slab of `ws` (fp32, pp_wgrad_ws_floats(d) elements, contents irrelevant) and an ordered pass adds the
+   * slabs into dW / dbias; without the mode, or where nothing is split, ws is not touched and may be NULL. */
+  float* ws; long long ws_floats;
 } pp_wgrad_desc;
 int pp_wgrad(const pp_wgrad_desc* d, pp_stream_t s);
+/* workspace (floats) pp_wgrad needs for `d` in the deterministic mode; 0 when it needs none (mode off, or no split) */
+long long pp_wgrad_ws_floats(const pp_wgrad_desc* d);
 int pp_wgrad_xbn_supported(const pp_wgrad_desc* d);
 
 /* ---- weight preparation (fp32 master -> bf16 operand layouts) and gradient un-preparation */
@@ -285,9 +297,10 @@ int pp_conv0_apply(const float* wave, int B, int L, int T0, const float* w, cons
 int pp_conv0_bwd_reduce(const float* wave, int B, int L, int T0, const float* w, const float* stats,
                         const float* gamma, const float* beta, float eps, const void* dout, float* red,
                         pp_stream_t s);
+/* ws: fp32 [B][512 * 10], needed only in the deterministic mode (per-clip partial rows of dw, summed in clip order) */
 int pp_conv0_bwd_apply(const float* wave, int B, int L, int T0, const float* w, const float* stats,
                        const float* gamma, const float* beta, float eps, const void* dout, const float* red,
-                       float* dw, float* dgamma, float* dbeta, pp_stream_t s);
+                       float* dw, float* dgamma, float* dbeta, float* ws, pp_stream_t s);
 
 /* ---- positional conv weight-norm (dim=2): w = g * v / ||v||_{(0,1)} --------------------- */
 /* v [768][48][128], g [128] -> norm [128], out bf16 operand [768][128][48] (pp_igemm layout) */
@@ -365,7 +378,7 @@ typedef struct pp_tensor_list {
  * count per tensor (pig/optimization.py:120-128), and tensors that skipped steps (LayerDrop) lag behind in the schedule;
  * with it every tensor of a parameter group goes into one launch.  NULL: lr_scheduled for all. */
 int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tensor, const long long* chunk_off,
-                     int n_chunks, int chunk, float* norms /* [n_tensors] scratch */, float lr_scheduled,
+                     int n_chunks, int chunk, float* norms /* [n_tensors + n_chunks] scratch (the chunk part: deterministic mode) */, float lr_scheduled,
                      float b1, float b2, float eps, float weight_decay, float max_grad_norm,
                      const float* lr_per_tensor,
                      const float* skip_flag /* optional (device): != 0 -> the whole step is a no-op (fp16 overflow) */,

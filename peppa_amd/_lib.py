@@ -48,7 +48,7 @@ class WGradDesc(C.Structure):
         ("x_s", C.c_longlong), ("dy_s", C.c_longlong), ("dw_s", C.c_longlong),
         ("dbias", C.c_void_p), ("dbias_s", C.c_longlong),
         ("x_bn_scale", C.c_void_p), ("x_bn_shift", C.c_void_p), ("x_bn_relu", C.c_int),
-        ("ptr_table", C.c_void_p)]
+        ("ptr_table", C.c_void_p), ("ws", C.c_void_p), ("ws_floats", C.c_longlong)]
 
 
 class TensorList(C.Structure):
@@ -68,6 +68,7 @@ SIGNATURES = {
     "pp_set_option": [C.c_char_p, I],
     "pp_igemm": [C.POINTER(IGemmDesc), P],
     "pp_wgrad": [C.POINTER(WGradDesc), P],
+    "pp_wgrad_ws_floats": [C.POINTER(WGradDesc)],
     "pp_igemm_abn_supported": [C.POINTER(IGemmDesc)],
     "pp_wgrad_xbn_supported": [C.POINTER(WGradDesc)],
     "pp_prep_conv_weight": [P, I, I, I, P, I, I, I, I, F, P],
@@ -114,7 +115,7 @@ SIGNATURES = {
     "pp_conv0_stats": [P, I, I, I, P, P, P],
     "pp_conv0_apply": [P, I, I, I, P, P, P, P, F, P, P],
     "pp_conv0_bwd_reduce": [P, I, I, I, P, P, P, P, F, P, P, P],
-    "pp_conv0_bwd_apply": [P, I, I, I, P, P, P, P, F, P, P, P, P, P, P],
+    "pp_conv0_bwd_apply": [P, I, I, I, P, P, P, P, F, P, P, P, P, P, P, P],
     "pp_weightnorm_fwd": [P, P, I, I, I, P, P, P],
     "pp_weightnorm_bwd": [P, P, P, P, I, I, I, P, P, P, P],
     "pp_spatial_mean_fwd": [P, P, I, I, I, I, I, P],
@@ -135,7 +136,7 @@ SIGNATURES = {
     "pp_triplet_accuracy": [P, P, P, I, I, I, P, P],
     "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P, P, P],
 }
-_RESTYPE = {"pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z}
+_RESTYPE = {"pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z, "pp_wgrad_ws_floats": L}
 _NO_STATUS = set(_RESTYPE) | {"pp_version", "pp_dtype"}
 
 _libs = {}

@@ -17,6 +17,8 @@ extern "C" int pp_dtype(void) { return PP_DTYPE_F16; }
 extern "C" int pp_dtype(void) { return PP_DTYPE_BF16; }
 #endif
 
+extern int pp_opt_deterministic;
+
 namespace {
 
 inline int sgrid(long long n, int per = 256) {
@@ -397,6 +399,7 @@ extern "C" int pp_colsum_bf16(const void* x, long long M, int N, int ld, float* 
   if (e != hipSuccess) { pp_set_error("pp_colsum_bf16: memset failed"); return PP_ERR_HIP; }
   int nblk = (int)((M + 63) / 64);
   if (nblk > 1024) nblk = 1024;
+  if (pp_opt_deterministic) nblk = 1;     // one workgroup, rows in order: a single adder per column
   const int rows_per_blk = (int)((M + nblk - 1) / nblk);
   hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, S_, (const h16raw*)x, M, N, ld, rows_per_blk, out);
   PP_LAUNCH_CHECK();

@@ -6,6 +6,8 @@
 //   pig/loss.py:33-55    TripletLoss = contrastive(cosine_matrix(V, A))
 #include "common.h"
 
+extern int pp_opt_deterministic;
+
 namespace {
 
 // C(m,n) (+)= act(sum_k A(m,k) B(k,n) + bias[n]); arbitrary strides (transposes by stride).
@@ -98,6 +100,7 @@ int sgemm(hipStream_t s, const float* A, long long sa_m, long long sa_k, const f
   return PP_OK;
 }
 inline int pick_ksplit(int M, int N, int K) {
+  if (pp_opt_deterministic) return 1;      // split-K sums its partial products with atomics
   const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
   int ks = 512 / (tiles > 0 ? tiles : 1);
   const int maxk = (K + 63) / 64;
@@ -116,7 +119,7 @@ __global__ void colsum_f32_kernel(const float* __restrict__ X, int M, int N, int
 }
 int colsum_f32(hipStream_t s, const float* X, int M, int N, int ld, float* out) {
   if (hipMemsetAsync(out, 0, (size_t)N * 4, s) != hipSuccess) { pp_set_error("colsum_f32: memset failed"); return PP_ERR_HIP; }
-  const int rpb = 32;
+  const int rpb = pp_opt_deterministic ? M : 32;     // deterministic: one workgroup, rows in order
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, s, X, M, N, ld, rpb, out);
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void loss_prep_kernel(const float* __restrict_
 // (~1e-7, inside the 1e-6 tolerance against the live reference's golden vectors; the loss is continuous in it).
 // Launch 2: one 32 x 32 tile of S per workgroup; epilogue = both hinges, G (zero diagonal), active counts, loss partial.
 __global__ __launch_bounds__(256) void loss_tile_kernel(const LossWs w, const float* __restrict__ diag, float* __restrict__ loss,
-                                                        int N, int D, float margin) {
+                                                        int N, int D, float margin, float* __restrict__ partials) {
   __shared__ float As[32][17];
   __shared__ float Bs[16][33];
   __shared__ float red[4];
@@ -381,7 +384,18 @@ __global__ __launch_bounds__(256) void loss_tile_kernel(const LossWs w, const fl
   cc += __shfl_xor(cc, 16); cc += __shfl_xor(cc, 32);   // column n: the four lane groups
   if (lane < 16 && n < N && cc != 0.f) atomicAdd(w.colc + n, cc);
   part = block_sum<4>(part, red);
+  if (partials) {      // deterministic: one partial per tile, added in tile order by loss_sum_kernel
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = part * inv;
+    return;
+  }
   if (threadIdx.x == 0 && part != 0.f) atomicAdd(loss, part * inv);
+}
+__global__ void loss_sum_kernel(const float* __restrict__ partials, int n, float* loss) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += partials[i];
+    loss[0] = s;
+  }
 }
 __global__ void scale_f32_kernel(float* x, const float* sc, long long n) {
   const float k = sc[0];
@@ -479,7 +493,11 @@ extern "C" int pp_triplet_loss_fwd(const float* V, const float* A, int N, int D,
   const LossWs w = loss_ws(ws, N, D);
   // two launches (the N = world x B global loss sits between the embedding all-gather and the backward pass)
   hipLaunchKernelGGL(loss_prep_kernel, dim3(N), dim3(256), 0, S_, V, A, w, loss, D);
-  hipLaunchKernelGGL(loss_tile_kernel, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, S_, w, (const float*)w.diag, loss, N, D, margin);
+  // (deterministic mode: the tiles' loss partials meet in the dVn area of the workspace, which only the backward pass uses)
+  const int nt = (N + 31) / 32;
+  float* const partials = (pp_opt_deterministic && (size_t)nt * nt <= (size_t)N * D) ? w.dVn : nullptr;
+  hipLaunchKernelGGL(loss_tile_kernel, dim3(nt, nt), dim3(256), 0, S_, w, (const float*)w.diag, loss, N, D, margin, partials);
+  if (partials) hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, S_, (const float*)partials, nt * nt, loss);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

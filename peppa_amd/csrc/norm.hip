@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* wave
 __global__ __launch_bounds__(256) void conv0_bwd_apply_kernel(const float* wave, int L, int T0, const float* w,
                                                               const float* stats, const float* gamma, const float* beta,
                                                               float eps, const h16raw* dout, const float* red, float* dw,
-                                                              float* dgamma, float* dbeta) {
+                                                              float* dgamma, float* dbeta, float* ws) {
   __shared__ float xs[(TT0 - 1) * S0 + K0];
   const int c = threadIdx.x * 2;
   const GN0 g = gn0_load(stats, blockIdx.y, c, T0, eps);
@@ -338,11 +338,34 @@ __global__ __launch_bounds__(256) void conv0_bwd_apply_kernel(const float* wave,
       dw1[k] += dy1 * xv;
     }
   });
+  if (ws) {     // deterministic: this clip's partial row (gridDim.x == 1); conv0_bwd_sum_kernel adds the clips in order
+    float* wp = ws + (long long)blockIdx.y * (C0 * K0);
+#pragma unroll
+    for (int k = 0; k < K0; ++k) { wp[c * K0 + k] = dw0[k]; wp[(c + 1) * K0 + k] = dw1[k]; }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < K0; ++k) { atomicAdd(dw + c * K0 + k, dw0[k]); atomicAdd(dw + (c + 1) * K0 + k, dw1[k]); }
   if (blockIdx.x == 0) {
     atomicAdd(dbeta + c, rp[0]); atomicAdd(dgamma + c, rp[1]);
     atomicAdd(dbeta + c + 1, rp[2]); atomicAdd(dgamma + c + 1, rp[3]);
+  }
+}
+
+// deterministic tail of conv0_bwd_apply: dw[i] += sum_b ws[b][i]; dbeta / dgamma[c] += sum_b red[b][c][0 / 1], clips in order
+__global__ void conv0_bwd_sum_kernel(const float* __restrict__ ws, const float* __restrict__ red, int B, float* dw,
+                                     float* dgamma, float* dbeta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C0 * K0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += ws[(long long)b * (C0 * K0) + i];
+    dw[i] += s;
+  }
+  if (i < C0) {
+    float sb = 0.f, sg = 0.f;
+    for (int b = 0; b < B; ++b) { sb += red[((long long)b * C0 + i) * 2]; sg += red[((long long)b * C0 + i) * 2 + 1]; }
+    dbeta[i] += sb;
+    dgamma[i] += sg;
   }
 }
 
@@ -446,7 +469,9 @@ extern "C" int pp_softmax_bwd(const float* dP, int lds, const void* P, int ldp, 
   return PP_OK;
 }
 
+extern int pp_opt_deterministic;
 static int conv0_red_blocks(int T0, int B) {
+  if (pp_opt_deterministic) return 1;   // one workgroup per clip walks every tile: each (clip, channel) sum has ONE adder
   // enough workgroups to fill 256 CUs a few times over, few enough that the final atomics stay cheap
   const int ntiles = (T0 + TT0 - 1) / TT0;
   int per_b = (1024 + B - 1) / B;
@@ -482,10 +507,13 @@ extern "C" int pp_conv0_bwd_reduce(const float* wave, int B, int L, int T0, cons
 }
 extern "C" int pp_conv0_bwd_apply(const float* wave, int B, int L, int T0, const float* w, const float* stats,
                                   const float* gamma, const float* beta, float eps, const void* dout, const float* red,
-                                  float* dw, float* dgamma, float* dbeta, pp_stream_t s) {
+                                  float* dw, float* dgamma, float* dbeta, float* ws, pp_stream_t s) {
   if (int rc = conv0_check(B, L, T0, "pp_conv0_bwd_apply")) return rc;
+  PP_CHECK_ARG(!pp_opt_deterministic || ws, "pp_conv0_bwd_apply: the deterministic mode needs ws (fp32 [B][512 * 10])");
+  float* const slab = pp_opt_deterministic ? ws : nullptr;
   hipLaunchKernelGGL(conv0_bwd_apply_kernel, dim3(conv0_red_blocks(T0, B), B), dim3(256), 0, S_, wave, L, T0, w, stats, gamma, beta,
-                     eps, (const h16raw*)dout, red, dw, dgamma, dbeta);
+                     eps, (const h16raw*)dout, red, dw, dgamma, dbeta, slab);
+  if (slab) hipLaunchKernelGGL(conv0_bwd_sum_kernel, dim3((C0 * K0 + 255) / 256), dim3(256), 0, S_, slab, red, B, dw, dgamma, dbeta);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -495,7 +523,7 @@ extern "C" int pp_weightnorm_fwd(const float* v, const float* g, int Co, int Ci,
   PP_CHECK_ARG(Co > 0 && Ci > 0 && Kk > 0 && Kk <= 1024, "pp_weightnorm_fwd: sizes");
   if (hipMemsetAsync(norm, 0, (size_t)Kk * 4, S_) != hipSuccess) { pp_set_error("pp_weightnorm_fwd: memset"); return PP_ERR_HIP; }
   const long long rows = (long long)Co * Ci;
-  const int rpb = 64;
+  const int rpb = pp_opt_deterministic ? (int)rows : 64;     // deterministic: one workgroup, rows in order
   hipLaunchKernelGGL(wn_sumsq_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(Kk), 0, S_, v, rows, Kk, rpb, norm);
   hipLaunchKernelGGL(wn_sqrt_kernel, dim3((Kk + 255) / 256), dim3(256), 0, S_, norm, Kk);
   const long long n = rows * Kk;
@@ -509,7 +537,7 @@ extern "C" int pp_weightnorm_bwd(const float* dwt, const float* v, const float* 
   PP_CHECK_ARG(Co > 0 && Ci > 0 && Kk > 0 && Kk <= 1024 && dot_ws, "pp_weightnorm_bwd: sizes");
   if (hipMemsetAsync(dot_ws, 0, (size_t)Kk * 4, S_) != hipSuccess) { pp_set_error("pp_weightnorm_bwd: memset"); return PP_ERR_HIP; }
   const long long rows = (long long)Co * Ci;
-  const int rpb = 64;
+  const int rpb = pp_opt_deterministic ? (int)rows : 64;
   hipLaunchKernelGGL(wn_bwd_reduce_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(Kk), 0, S_, dwt, v, Co, Ci, Kk, rpb,
                      dot_ws);
   const long long n = rows * Kk;

@@ -4,6 +4,8 @@
 // update = m/(sqrt(v)+eps) + wd*p, p -= lr_scheduled*update; no bias correction.
 #include "common.h"
 
+extern int pp_opt_deterministic;
+
 namespace {
 
 // Both kernels stream with 16-byte accesses where the tensor allows it (every pointer 16-byte aligned; chunk offsets are
@@ -15,7 +17,7 @@ __device__ __forceinline__ bool aligned16(const void* a, const void* b, const vo
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const pp_tensor_list tl, const int* __restrict__ chunk_tensor,
                                                     const long long* __restrict__ chunk_off, int chunk, float* norms,
-                                                    const float* __restrict__ skip) {
+                                                    const float* __restrict__ skip, float* __restrict__ partials) {
   __shared__ float red[4];
   if (skip && *skip != 0.f) return;     // an overflowed fp16 step: nothing is updated (uniform for the whole grid)
   const int t = chunk_tensor[blockIdx.x];
@@ -36,6 +38,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const pp_tensor_list tl, con
   }
   for (long long i = done + threadIdx.x; i < end; i += 256) { const float v = g[i]; s += v * v; }
   s = block_sum<4>(s, red);
+  if (partials) {       // deterministic: one partial per chunk; bertadam_kernel adds a tensor's chunks in order
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    return;
+  }
   if (threadIdx.x == 0) atomicAdd(norms + t, s);
 }
 
@@ -43,7 +49,8 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const pp_tensor_list tl, 
                                                        const long long* __restrict__ chunk_off, int chunk,
                                                        const float* __restrict__ norms, float lr, float b1, float b2, float eps,
                                                        float wd, float max_norm, const float* __restrict__ lr_t,
-                                                       const float* __restrict__ skip) {
+                                                       const float* __restrict__ skip, const float* __restrict__ partials,
+                                                       int n_chunks) {
   if (skip && *skip != 0.f) return;
   const int t = chunk_tensor[blockIdx.x];
   if (lr_t) lr = lr_t[t];   // per-tensor scheduled learning rate (tensors whose step counts differ share one launch)
@@ -55,7 +62,17 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const pp_tensor_list tl, 
   float* v = tl.v[t];
   float coef = 1.f;
   if (max_norm > 0.f) {
-    coef = max_norm / (sqrtf(norms[t]) + 1e-6f);
+    float nsq;
+    if (partials) {     // the tensor's chunks are consecutive blocks: sum their partial squares first to last
+      int c0 = blockIdx.x, c1 = blockIdx.x;
+      while (c0 > 0 && chunk_tensor[c0 - 1] == t) --c0;
+      while (c1 + 1 < n_chunks && chunk_tensor[c1 + 1] == t) ++c1;
+      nsq = 0.f;
+      for (int c = c0; c <= c1; ++c) nsq += partials[c];
+    } else {
+      nsq = norms[t];
+    }
+    coef = max_norm / (sqrtf(nsq) + 1e-6f);
     coef = coef < 1.f ? coef : 1.f;
   }
   const long long end = off + chunk < n ? off + chunk : n;
@@ -170,12 +187,14 @@ extern "C" int pp_bertadam_step(const pp_tensor_list* tl, const int* chunk_tenso
                                 float max_grad_norm, const float* lr_per_tensor, const float* skip_flag, pp_stream_t s) {
   PP_CHECK_ARG(tl && tl->n_tensors > 0 && n_chunks > 0 && chunk > 0 && norms, "pp_bertadam_step: bad arguments");
   hipStream_t st = (hipStream_t)s;
+  // deterministic mode: the chunks' partial squares go to norms[n_tensors ..] and every block adds its tensor's in order
+  float* const partials = pp_opt_deterministic ? norms + tl->n_tensors : nullptr;
   if (max_grad_norm > 0.f) {
     if (hipMemsetAsync(norms, 0, (size_t)tl->n_tensors * 4, st) != hipSuccess) { pp_set_error("pp_bertadam_step: memset"); return PP_ERR_HIP; }
-    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms, skip_flag);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms, skip_flag, partials);
   }
   hipLaunchKernelGGL(bertadam_kernel, dim3(n_chunks), dim3(256), 0, st, *tl, chunk_tensor, chunk_off, chunk, norms, lr_scheduled,
-                     b1, b2, eps, weight_decay, max_grad_norm, lr_per_tensor, skip_flag);
+                     b1, b2, eps, weight_decay, max_grad_norm, lr_per_tensor, skip_flag, (const float*)partials, n_chunks);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

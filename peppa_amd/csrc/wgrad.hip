@@ -14,8 +14,9 @@ int pp_validate_gather(const pp_gather& g, int K, const char* who);
 extern int pp_opt_xcd_remap_wgrad;
 extern int pp_opt_ring_wgrad;
 extern int pp_opt_sw_wgrad;
-int pp_wgrad_sw_try(const pp_wgrad_desc& d, hipStream_t s);
-int pp_wgrad_tw_try(const pp_wgrad_desc& d, hipStream_t s, bool force);
+extern int pp_opt_deterministic;
+int pp_wgrad_sw_try(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query);
+int pp_wgrad_tw_try(const pp_wgrad_desc& d, hipStream_t s, bool force, long long* ws_query);
 bool pp_wgrad_tw_ok(const pp_wgrad_desc& d, bool force);
 
 namespace {
@@ -78,6 +79,10 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
   const h16raw* dY = (const h16raw*)p.dY + z * p.dy_s;
   float* __restrict__ dW = p.dW + z * p.dw_s;
   float* dbias_z = BIAS ? p.dbias + z * p.dbias_s : nullptr;
+  // deterministic mode: this (problem, split)'s slab of p.ws -- Ni rows of ldw floats, then Ni bias floats
+  const long long slab_floats = (long long)p.Ni * p.ldw + p.Ni;
+  const long long slab_w = ((long long)z * (gridDim.x / (nblk_i * nblk_j)) + split) * slab_floats;
+  const long long slab_b = slab_w + (long long)p.Ni * p.ldw;
   if (p.ptr_table) {      // grouped launch: problem z has its own operands (uniform scalar loads)
     const unsigned long long* e = p.ptr_table + 4 * z;
     X = (const h16raw*)e[0];
@@ -279,7 +284,10 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
       for (int i = tid; i < TI; i += 256) {
         float v = 0.f;
         for (int r = 0; r < MS; ++r) v += part[(r * 2 * WI + (i >> 3)) * 8 + (i & 7)];
-        if (i0 + i < p.Ni) atomicAdd(dbias_z + i0 + i, v);
+        if (i0 + i < p.Ni) {
+          if (p.ws) p.ws[slab_b + i0 + i] = v;            // deterministic: this split's slab, summed in split order later
+          else atomicAdd(dbias_z + i0 + i, v);
+        }
       }
     __syncthreads();
   }
@@ -310,9 +318,44 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j = j0 + h * 64 + lane;
-        if (j < p.Kj) atomicAdd(dW + (long long)i * p.ldw + j, tile[row * TJ + h * 64 + lane]);
+        if (j < p.Kj) {
+          if (p.ws) p.ws[slab_w + (long long)i * p.ldw + j] = tile[row * TJ + h * 64 + lane];
+          else atomicAdd(dW + (long long)i * p.ldw + j, tile[row * TJ + h * 64 + lane]);
+        }
       }
     }
+  }
+}
+
+// Deterministic mode: out[z][i][j] += sum over the splits, in split order, of the slabs the kernels above stored.
+// Slab (z, split) = ws[(z * nsplit + split) * slab_floats ..]: Ni rows of ldw floats, then (bias) Ni floats.
+__global__ __launch_bounds__(256) void wgrad_slab_sum_kernel(const float* __restrict__ ws, const int nsplit, const long long slab_floats,
+                                                             const int Ni, const int Kj, const int ldw, float* dW,
+                                                             const long long dw_s, float* dbias, const long long dbias_s,
+                                                             const unsigned long long* __restrict__ ptr_table) {
+  const int z = blockIdx.z;
+  float* out = dW + z * dw_s;
+  float* bout = dbias ? dbias + z * dbias_s : nullptr;
+  if (ptr_table) {
+    out = (float*)ptr_table[4 * z + 2];
+    bout = dbias ? (float*)ptr_table[4 * z + 3] : nullptr;
+  }
+  const float* base = ws + (long long)z * nsplit * slab_floats;
+  const long long n = (long long)Ni * Kj;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n + (bout ? Ni : 0); e += (long long)gridDim.x * 256) {
+    long long off;
+    float* dst;
+    if (e < n) {
+      const int i = (int)(e / Kj), j = (int)(e - (long long)i * Kj);
+      off = (long long)i * ldw + j;
+      dst = out + off;
+    } else {
+      off = (long long)Ni * ldw + (e - n);
+      dst = bout + (e - n);
+    }
+    float sum = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) sum += base[sp * slab_floats + off];
+    *dst += sum;
   }
 }
 
@@ -624,8 +667,19 @@ int pick_wi(int n16) {
   return best;
 }
 
+inline long long slab_floats_total(const pp_wgrad_desc& d, int msplit) {
+  return ((long long)d.Ni * d.ldw + d.Ni) * msplit * (d.nbatch > 0 ? d.nbatch : 1);
+}
+inline void launch_slab_sum(const pp_wgrad_desc& d, int msplit, hipStream_t s) {
+  const long long n = (long long)d.Ni * d.Kj + (d.dbias ? d.Ni : 0);
+  long long gx = (n + 255) / 256;
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(wgrad_slab_sum_kernel, dim3((unsigned)gx, 1, (unsigned)(d.nbatch > 0 ? d.nbatch : 1)), dim3(256), 0, s, (const float*)d.ws,
+                     msplit, (long long)d.Ni * d.ldw + d.Ni, d.Ni, d.Kj, d.ldw, d.dW, d.dw_s, d.dbias, d.dbias_s, d.ptr_table);
+}
+
 template <int WI>
-int launch_wi(const pp_wgrad_desc& d, hipStream_t s) {
+int launch_wi(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query = nullptr) {
   const int nblk_i = (d.Ni + 16 * WI - 1) / (16 * WI);
   const int nblk_j = (d.Kj + TJ - 1) / TJ;
   int msplit = d.msplit;
@@ -649,12 +703,22 @@ int launch_wi(const pp_wgrad_desc& d, hipStream_t s) {
   wg.dRt = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rt));
   const long long gx = (long long)nblk_i * nblk_j * msplit;
   dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(256);
-  if (d.g.mode == PP_DENSE) {
-    if (d.dbias) hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, true>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
-    else hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+  pp_wgrad_desc k = d;                       // what the kernel sees: ws only when this launch really is split
+  const bool slabs = pp_opt_deterministic && msplit > 1;
+  if (ws_query) { *ws_query = slabs ? slab_floats_total(d, msplit) : 0; return PP_OK; }
+  if (slabs) {
+    PP_CHECK_ARG(d.ws && d.ws_floats >= slab_floats_total(d, msplit), "pp_wgrad: deterministic mode needs ws of pp_wgrad_ws_floats(d) = %lld floats",
+                 slab_floats_total(d, msplit));
   } else {
-    hipLaunchKernelGGL((wgrad_kernel<WI, PP_CONV_FWD, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+    k.ws = nullptr;
   }
+  if (d.g.mode == PP_DENSE) {
+    if (d.dbias) hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, true>), grid, block, 0, s, k, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+    else hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, false>), grid, block, 0, s, k, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+  } else {
+    hipLaunchKernelGGL((wgrad_kernel<WI, PP_CONV_FWD, false>), grid, block, 0, s, k, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+  }
+  if (slabs) launch_slab_sum(d, msplit, s);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -708,11 +772,11 @@ extern "C" int pp_wgrad_xbn_supported(const pp_wgrad_desc* dp) {
   return xbn_ok(d) ? 1 : 0;
 }
 
-extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
+static int wgrad_dispatch(const pp_wgrad_desc* dp, pp_stream_t stream, long long* ws_query) {
   PP_CHECK_ARG(dp != nullptr, "pp_wgrad: null descriptor");
   pp_wgrad_desc d = *dp;
   PP_CHECK_ARG(d.M > 0 && d.Ni > 0 && d.Kj > 0, "pp_wgrad: bad sizes");
-  PP_CHECK_ARG(d.ptr_table || (d.X && d.dY && d.dW), "pp_wgrad: null operand");
+  PP_CHECK_ARG(ws_query || d.ptr_table || (d.X && d.dY && d.dW), "pp_wgrad: null operand");
   PP_CHECK_ARG(!d.ptr_table || (d.g.mode == PP_DENSE && d.nbatch >= 1 && !d.x_bn_scale && !d.x_bn_shift),
                "pp_wgrad: a pointer table (grouped launch) needs a dense gather, nbatch >= 1 and no fused BatchNorm");
   PP_CHECK_ARG(d.ldy % 8 == 0 && d.ldy >= ((d.Ni + 7) & ~7), "pp_wgrad: ldy=%d too small/unaligned for Ni=%d", d.ldy, d.Ni);
@@ -738,16 +802,16 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
     PP_CHECK_ARG(d.x_bn_scale && d.x_bn_shift && xbn_ok(d),
                  "pp_wgrad: x_bn_scale / x_bn_shift (BatchNorm apply of X's producer) is not available for this problem: "
                  "ask pp_wgrad_xbn_supported first");
-    return pp_wgrad_tw_try(d, s, pp_opt_sw_wgrad == 1);
+    return pp_wgrad_tw_try(d, s, pp_opt_sw_wgrad == 1, ws_query);
   }
   if (pp_opt_sw_wgrad && (long long)d.M >= pp_opt_sw_wgrad && !d.ptr_table) {   // (1,3,3) stride-1 convs: window along m
-    const int rc_sw = pp_wgrad_sw_try(d, s);
+    const int rc_sw = pp_wgrad_sw_try(d, s, ws_query);
     if (rc_sw != 1) return rc_sw;
-    const int rc_tw = pp_wgrad_tw_try(d, s, pp_opt_sw_wgrad == 1);                    // (3,1,1) stride-1 convs: window over time
+    const int rc_tw = pp_wgrad_tw_try(d, s, pp_opt_sw_wgrad == 1, ws_query);          // (3,1,1) stride-1 convs: window over time
     if (rc_tw != 1) return rc_tw;
   }
   const int n16 = (d.Ni + 15) / 16;
-  if (pp_opt_ring_wgrad && d.nbatch == 1 && !d.ptr_table && n16 > 4 && (long long)d.M >= pp_opt_ring_wgrad) {
+  if (pp_opt_ring_wgrad && !pp_opt_deterministic && d.nbatch == 1 && !d.ptr_table && n16 > 4 && (long long)d.M >= pp_opt_ring_wgrad) {
     // ring tiles: 128 or 144 rows of dW (less padding wins) x 192 or 256 columns (ditto; 192 on ties)
     const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
     const int j6 = ((d.Kj + 191) / 192) * 192, j8 = ((d.Kj + 255) / 256) * 256;
@@ -756,11 +820,28 @@ extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) {
     return v6 ? launch_ring<8, 6>(d, s) : launch_ring<8, 8>(d, s);
   }
   switch (pick_wi(n16)) {
-    case 15: return launch_wi<15>(d, s);
-    case 9: return launch_wi<9>(d, s);
-    case 8: return launch_wi<8>(d, s);
-    case 4: return launch_wi<4>(d, s);
-    case 3: return launch_wi<3>(d, s);
-    default: return launch_wi<2>(d, s);
+    case 15: return launch_wi<15>(d, s, ws_query);
+    case 9: return launch_wi<9>(d, s, ws_query);
+    case 8: return launch_wi<8>(d, s, ws_query);
+    case 4: return launch_wi<4>(d, s, ws_query);
+    case 3: return launch_wi<3>(d, s, ws_query);
+    default: return launch_wi<2>(d, s, ws_query);
   }
+}
+
+extern "C" int pp_wgrad(const pp_wgrad_desc* dp, pp_stream_t stream) { return wgrad_dispatch(dp, stream, nullptr); }
+
+extern "C" long long pp_wgrad_ws_floats(const pp_wgrad_desc* dp) {
+  if (!pp_opt_deterministic) return 0;
+  long long need = 0;
+  const int rc = wgrad_dispatch(dp, nullptr, &need);
+  return rc == PP_OK ? need : 0;
+}
+
+void pp_wgrad_slab_sum(const float* ws, int nsplit, long long slab_floats, int Ni, int Kj, int ldw, float* dW, hipStream_t s) {
+  const long long n = (long long)Ni * Kj;
+  long long gx = (n + 255) / 256;
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(wgrad_slab_sum_kernel, dim3((unsigned)gx, 1, 1), dim3(256), 0, s, ws, nsplit, slab_floats, Ni, Kj, ldw, dW, 0LL,
+                     (float*)nullptr, 0LL, (const unsigned long long*)nullptr);
 }

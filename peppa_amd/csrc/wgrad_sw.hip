@@ -19,6 +19,8 @@
 #include <type_traits>
 
 extern int pp_opt_xcd_remap_wgrad;
+extern int pp_opt_deterministic;
+void pp_wgrad_slab_sum(const float* ws, int nsplit, long long slab_floats, int Ni, int Kj, int ldw, float* dW, hipStream_t s);
 
 namespace {
 
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const h16raw* __restric
                                                           float* __restrict__ dW, const SwGeom g, const int Ni,
                                                           const int ldy, const int ldw, const int nblk_i,
                                                           const int nblk_c, const int rows_per_split,
-                                                          const int xcd_remap) {
+                                                          const int xcd_remap, float* __restrict__ slab) {
   constexpr int TI = 16 * WI;
   constexpr int PS = (WI & 1) ? TI * 2 : TI * 2 + 32;   // dY slab row stride (32 x odd)
   constexpr int P_BYTES = MS * PS;
@@ -309,13 +311,17 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const h16raw* __restric
       const int row = idx / 576, col = idx - row * 576;
       const int i = i0 + a * 16 + ((row + split) & 15);          // splits start at different rows
       const int tap = col >> 6, c = c0 + (col & 63);
-      if (i < Ni && c < g.cg) atomicAdd(dW + (long long)i * ldw + tap * g.cg + c, stage[((row + split) & 15) * 576 + col]);
+      if (i < Ni && c < g.cg) {
+        const long long o = (long long)i * ldw + tap * g.cg + c;
+        if (slab) slab[(long long)split * Ni * ldw + o] = stage[((row + split) & 15) * 576 + col];      // deterministic mode
+        else atomicAdd(dW + o, stage[((row + split) & 15) * 576 + col]);
+      }
     }
   }
 }
 
 template <int WI>
-int launch_sw(const pp_wgrad_desc& d, hipStream_t s) {
+int launch_sw(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query) {
   const pp_gather& gg = d.g;
   SwGeom g;
   g.W = gg.Gw; g.H = gg.Gh; g.M = d.M; g.cstride = gg.cstride; g.cg = gg.cg;
@@ -339,8 +345,13 @@ int launch_sw(const pp_wgrad_desc& d, hipStream_t s) {
   msplit = (int)((steps + sps - 1) / sps);
   const int rows_per_split = (int)(sps * MS);
   dim3 grid((unsigned)(tiles * msplit), 1, 1), block(NT);
+  const bool slabs = pp_opt_deterministic && msplit > 1;
+  const long long need = slabs ? (long long)msplit * d.Ni * d.ldw : 0;
+  if (ws_query) { *ws_query = need; return PP_OK; }
+  if (slabs) PP_CHECK_ARG(d.ws && d.ws_floats >= need, "pp_wgrad: deterministic mode needs ws of pp_wgrad_ws_floats(d) = %lld floats", need);
   hipLaunchKernelGGL((wgrad_sw_kernel<WI>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
-                     d.ldw, nblk_i, nblk_c, rows_per_split, pp_opt_xcd_remap_wgrad);
+                     d.ldw, nblk_i, nblk_c, rows_per_split, pp_opt_xcd_remap_wgrad, slabs ? d.ws : (float*)nullptr);
+  if (slabs) pp_wgrad_slab_sum(d.ws, msplit, (long long)d.Ni * d.ldw, d.Ni, d.Kj, d.ldw, d.dW, s);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -349,7 +360,7 @@ int launch_sw(const pp_wgrad_desc& d, hipStream_t s) {
 
 // Returns PP_OK if the sliding-window kernel took the problem, 1 if the shape is not one it handles (the caller falls
 // through to the generic kernel), or a negative error.
-int pp_wgrad_sw_try(const pp_wgrad_desc& d, hipStream_t s) {
+int pp_wgrad_sw_try(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query) {
   const pp_gather& g = d.g;
   const bool shape_ok = g.mode == PP_CONV_FWD && d.nbatch == 1 && !d.dbias && g.kt == 1 && g.kh == 3 && g.kw == 3 &&
                         g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 && g.ph == 1 && g.pw == 1 && g.Gt == g.Rt &&
@@ -358,5 +369,5 @@ int pp_wgrad_sw_try(const pp_wgrad_desc& d, hipStream_t s) {
   if (!shape_ok) return 1;
   const int n16 = (d.Ni + 15) / 16;
   const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
-  return c9 <= c8 ? launch_sw<9>(d, s) : launch_sw<8>(d, s);
+  return c9 <= c8 ? launch_sw<9>(d, s, ws_query) : launch_sw<8>(d, s, ws_query);
 }

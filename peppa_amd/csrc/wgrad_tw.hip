@@ -16,6 +16,8 @@
 #include <type_traits>
 
 extern int pp_opt_xcd_remap_wgrad;
+extern int pp_opt_deterministic;
+void pp_wgrad_slab_sum(const float* ws, int nsplit, long long slab_floats, int Ni, int Kj, int ldw, float* dW, hipStream_t s);
 
 namespace {
 
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const h16raw* __restric
                                                           const int ldy, const int ldw, const int nblk_i,
                                                           const int nblk_c, const int steps_per_split,
                                                           const int xcd_remap, const float* __restrict__ bn_scale,
-                                                          const float* __restrict__ bn_shift, const int bn_relu) {
+                                                          const float* __restrict__ bn_shift, const int bn_relu,
+                                                          float* __restrict__ slab) {
   constexpr int TI = 16 * WI;
   constexpr int PS = (WI & 1) ? TI * 2 : TI * 2 + 32;
   constexpr int PSLOT = MS * PS;
@@ -309,13 +312,17 @@ __global__ __launch_bounds__(NT, 1) void wgrad_tw_kernel(const h16raw* __restric
       const int row = (row0 + split) & 15;                        // splits start at different rows
       const int i = i0 + a * 16 + row;
       const int tap = col / CB, c = c0 + col - tap * CB;
-      if (i < Ni && c < g.cg) atomicAdd(dW + (long long)i * ldw + tap * g.cg + c, stage[row * (3 * CB) + col]);
+      if (i < Ni && c < g.cg) {
+        const long long o = (long long)i * ldw + tap * g.cg + c;
+        if (slab) slab[(long long)split * Ni * ldw + o] = stage[row * (3 * CB) + col];      // deterministic mode
+        else atomicAdd(dW + o, stage[row * (3 * CB) + col]);
+      }
     }
   }
 }
 
 template <int WI>
-int launch_tw(const pp_wgrad_desc& d, hipStream_t s) {
+int launch_tw(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query) {
   const pp_gather& gg = d.g;
   TwGeom g;
   g.T = gg.Gt; g.HW = gg.Gh * gg.Gw; g.NHB = (g.HW + MS - 1) / MS;
@@ -340,17 +347,23 @@ int launch_tw(const pp_wgrad_desc& d, hipStream_t s) {
   const int sps = (g.NS + msplit - 1) / msplit;
   msplit = (g.NS + sps - 1) / sps;
   dim3 grid((unsigned)(tiles * msplit), 1, 1), block(NT);
+  const bool slabs = pp_opt_deterministic && msplit > 1;
+  const long long need = slabs ? (long long)msplit * d.Ni * d.ldw : 0;
+  if (ws_query) { *ws_query = need; return PP_OK; }
+  if (slabs) PP_CHECK_ARG(d.ws && d.ws_floats >= need, "pp_wgrad: deterministic mode needs ws of pp_wgrad_ws_floats(d) = %lld floats", need);
+  float* const slab = slabs ? d.ws : nullptr;
   if (d.x_bn_scale) {
     if constexpr (WI == 4) {      // (64 rows of dW: the six-slot X ring does not fit beside the dY ring of 128)
       hipLaunchKernelGGL((wgrad_tw_kernel<WI, true>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
-                         d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad, d.x_bn_scale, d.x_bn_shift, d.x_bn_relu);
+                         d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad, d.x_bn_scale, d.x_bn_shift, d.x_bn_relu, slab);
     } else {
       pp_set_error("pp_wgrad: x_bn_scale / x_bn_shift need Ni <= 64 in the temporal sliding-window kernel");
       return PP_ERR_INVALID;
     }
   } else
     hipLaunchKernelGGL((wgrad_tw_kernel<WI, false>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
-                       d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad, (const float*)nullptr, (const float*)nullptr, 0);
+                       d.ldw, nblk_i, nblk_c, sps, pp_opt_xcd_remap_wgrad, (const float*)nullptr, (const float*)nullptr, 0, slab);
+  if (slabs) pp_wgrad_slab_sum(d.ws, msplit, (long long)d.Ni * d.ldw, d.Ni, d.Kj, d.ldw, d.dW, s);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -376,8 +389,8 @@ bool pp_wgrad_tw_ok(const pp_wgrad_desc& d, const bool force) {
 
 // PP_OK if the temporal sliding-window kernel took the problem, 1 if the shape is not one it handles, < 0 on error.
 // `force` (tests: pp_set_option("sw_wgrad", 1)) skips the is-it-worth-it rule.
-int pp_wgrad_tw_try(const pp_wgrad_desc& d, hipStream_t s, const bool force) {
+int pp_wgrad_tw_try(const pp_wgrad_desc& d, hipStream_t s, const bool force, long long* ws_query) {
   if (!pp_wgrad_tw_ok(d, force)) return 1;
   const int n16 = (d.Ni + 15) / 16;
-  return n16 <= 4 ? launch_tw<4>(d, s) : launch_tw<8>(d, s);
+  return n16 <= 4 ? launch_tw<4>(d, s, ws_query) : launch_tw<8>(d, s, ws_query);
 }

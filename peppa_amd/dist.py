@@ -239,9 +239,10 @@ def enable_sync_bn(on=True):
     from . import layers as L
     if on and dist.is_available() and dist.is_initialized():
         L.SYNC_BN_REDUCE = lambda t: dist.all_reduce(t)
+        L.SYNC_BN_GATHER = lambda out, t: dist.all_gather_into_tensor(out, t)     # deterministic mode: partial rows, not sums
         L.SYNC_BN_WORLD = dist.get_world_size()
     else:
-        L.SYNC_BN_REDUCE, L.SYNC_BN_WORLD = None, 1
+        L.SYNC_BN_REDUCE, L.SYNC_BN_GATHER, L.SYNC_BN_WORLD = None, None, 1
 
 
 def default_buckets(net, device):

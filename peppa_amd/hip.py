@@ -54,6 +54,26 @@ def set_option(name, value):
     call("pp_set_option", name.encode(), int(value))
 
 
+DETERMINISTIC = False
+
+
+def set_deterministic(on=True):
+    """pp_set_option("deterministic", ...) in BOTH builds of the library + the workspaces the wrappers below then pass:
+    every sum that crosses workgroups is taken in a fixed order instead of by fp32 atomics, so two runs of the same step
+    give bitwise-identical losses, gradients and updates (include/peppa_hip.h; cost: DESIGN.md section 7).  Returns the
+    previous setting.  `mi355x: {deterministic: true}` in the yaml / `run.py --deterministic` switch it on."""
+    global DETERMINISTIC
+    prev, DETERMINISTIC = DETERMINISTIC, bool(on)
+    cur = _lib.PRECISION
+    for prec in ("bf16", "fp16"):
+        _lib.PRECISION = prec
+        try:
+            call("pp_set_option", b"deterministic", int(bool(on)))
+        finally:
+            _lib.PRECISION = cur
+    return prev
+
+
 def rup(x, m):
     return (x + m - 1) // m * m
 
@@ -207,6 +227,12 @@ def wgrad(X, dY, dW, M, Ni, Kj, g, ldy, ldw, *, msplit=0, nbatch=1, x_s=0, dy_s=
     d.X, d.dY, d.ldy, d.dW, d.ldw = _p(X, act16()), _p(dY, act16()), ldy, _p(dW, f32), ldw
     d.msplit, d.nbatch, d.x_s, d.dy_s, d.dw_s = msplit, nbatch, x_s, dy_s, dw_s
     d.dbias, d.dbias_s = _p(dbias, f32), dbias_s
+    ws = None
+    if DETERMINISTIC:       # slabs for the splits' partial tiles (pp_wgrad_desc.ws); nothing when the launch is not split
+        need = _lib.lib().pp_wgrad_ws_floats(C.byref(d))
+        if need > 0:
+            ws = torch.empty(need, dtype=f32, device=dW.device)
+            d.ws, d.ws_floats = ws.data_ptr(), need
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append(("wgrad", _MODE_NAMES[g.mode], M, Ni, Kj, nbatch, (g.kt, g.kh, g.kw), (g.st, g.sh, g.sw), g.cg))
     _profiled(f"{_wgrad_family(g)}<{_MODE_NAMES[g.mode]}> Ni={Ni} Kj={Kj}", 2.0 * M * Ni * Kj * nbatch,
@@ -429,8 +455,9 @@ def conv0_bwd_reduce(wave, B, L, T0, w, stats, gamma, beta, eps, dout, red):
 
 
 def conv0_bwd_apply(wave, B, L, T0, w, stats, gamma, beta, eps, dout, red, dw, dgamma, dbeta):
+    ws = torch.empty(B * 512 * 10, dtype=f32, device=wave.device) if DETERMINISTIC else None   # per-clip partial rows of dw
     call("pp_conv0_bwd_apply", _p(wave, f32), B, L, T0, _p(w, f32), _p(stats, f32), _p(gamma, f32), _p(beta, f32),
-         eps, _p(dout, act16()), _p(red, f32), _p(dw, f32), _p(dgamma, f32), _p(dbeta, f32), _s())
+         eps, _p(dout, act16()), _p(red, f32), _p(dw, f32), _p(dgamma, f32), _p(dbeta, f32), _p(ws, f32), _s())
 
 
 def weightnorm_fwd(v, g, Co, Ci, Kk, norm, out):

@@ -320,6 +320,12 @@ class BNSaved:
 # peppa_amd.dist.enable_sync_bn() sets both (tests plug in a stand-in to play two ranks in one process).
 SYNC_BN_REDUCE = None
 SYNC_BN_WORLD = 1
+# Deterministic mode (hip.set_deterministic): the ranks exchange their per-block PARTIAL rows instead of their sums
+# (`all_gather_into_tensor(out, t)`), and every rank finalizes over the concatenation -- exactly the partial rows, in
+# exactly the order, that ONE process running the global batch reduces (blocks are fixed-size runs of rows and the batch
+# is rank-major), so the statistics, and with them every activation and data gradient, agree bit for bit with that
+# process.  Costs world x the traffic of the sums (29 MB per rank for a layer-1 unit at batch 64): a checking mode.
+SYNC_BN_GATHER = None
 
 
 def _global_sums(partials, nblk, Cp):
@@ -328,6 +334,17 @@ def _global_sums(partials, nblk, Cp):
     H.partials_sum(partials, nblk, Cp, empty((64, 2, Cp), f32, partials), tot)
     SYNC_BN_REDUCE(tot)
     return tot
+
+
+def _global_partials(partials, nblk, Cp):
+    """[nblk][2][Cp] partial rows of this rank -> ([world * nblk][2][Cp] of every rank, rank-major, world * nblk)."""
+    out = empty((SYNC_BN_WORLD * nblk, 2, Cp), f32, partials)
+    SYNC_BN_GATHER(out, partials[:nblk].contiguous())
+    return out, SYNC_BN_WORLD * nblk
+
+
+def _ordered_sync():
+    return H.DETERMINISTIC and SYNC_BN_GATHER is not None
 
 
 def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momentum=0.1, update_running=True, apply=True):
@@ -342,7 +359,11 @@ def bn_fwd(y, partials, nblk, count, bn, *, relu, residual=None, eps=1e-5, momen
         H.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, eps, C, Cp, sv.scale, sv.shift)
     else:
         if SYNC_BN_REDUCE is not None:      # statistics of the global batch: sums and count over all ranks
-            partials, nblk, count = _global_sums(partials, nblk, Cp), 1, count * SYNC_BN_WORLD
+            if _ordered_sync():
+                partials, nblk = _global_partials(partials, nblk, Cp)
+                count = count * SYNC_BN_WORLD
+            else:
+                partials, nblk, count = _global_sums(partials, nblk, Cp), 1, count * SYNC_BN_WORLD
             sv.count = count
         ws = empty((64, 2, Cp), f32, y) if nblk > 256 else None
         H.bn_finalize(partials, nblk, Cp, count, C, Cp, bn.weight, bn.bias, eps, momentum,
@@ -364,7 +385,8 @@ def bn_bwd(dz, y, z, sv, gamma, *, relu, want_dres=False):
     if ready is not None:
         partials, nblk = ready             # (sum g, sum g * xhat) per 256 rows, from the data-gradient epilogue
     else:
-        nblk = min(2048, (M + 63) // 64)
+        # (deterministic mode: fixed 64-row blocks whatever M is, so that a rank's blocks are blocks of the global batch)
+        nblk = (M + 63) // 64 if H.DETERMINISTIC else min(2048, (M + 63) // 64)
         partials = empty((nblk, 2, Cp), f32, y)
         H.bn_bwd_reduce(dz, y, z, sv.mean, sv.rstd, sv.scale, sv.shift, relu, partials, nblk, M, Cp)
     dgamma, dbeta = empty((sv.C,), f32, y), empty((sv.C,), f32, y)
@@ -374,7 +396,11 @@ def bn_bwd(dz, y, z, sv, gamma, *, relu, want_dres=False):
         # dgamma / dbeta stay this rank's sums (the data-parallel all-reduce adds the ranks up); the coefficients of dy
         # -- the means of g and g * xhat -- are those of the global batch (sv.count already is the global count)
         scratch = empty((2, sv.C), f32, y)
-        H.bn_bwd_finalize(_global_sums(partials, nblk, Cp), 1, sv.count, sv.C, Cp, gamma, sv.rstd, scratch[0], scratch[1], coef)
+        if _ordered_sync():
+            gp, gn = _global_partials(partials, nblk, Cp)
+            H.bn_bwd_finalize(gp, gn, sv.count, sv.C, Cp, gamma, sv.rstd, scratch[0], scratch[1], coef)
+        else:
+            H.bn_bwd_finalize(_global_sums(partials, nblk, Cp), 1, sv.count, sv.C, Cp, gamma, sv.rstd, scratch[0], scratch[1], coef)
     dy = empty(y.shape, act16(), y)
     dres = empty(y.shape, act16(), y) if want_dres else None
     H.bn_bwd_apply(dz, y, z, sv.mean, sv.rstd, coef, sv.scale, sv.shift, relu, dy, dres, M, Cp)

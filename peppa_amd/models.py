@@ -427,6 +427,8 @@ class PeppaPig(_Base):
         self._logged = {}
         # optional `mi355x:` block (ignored by the reference): run the two encoders on separate HIP streams
         self._overlap = bool(extra.get('overlap_encoders', True))
+        if extra.get('deterministic'):      # bitwise-reproducible steps: ordered reductions instead of fp32 atomics
+            H.set_deterministic(True)
         self._side_stream = None
         # 16-bit operand type of the towers: "bf16" (default; BASELINE configs[1]) or "fp16" (the reference's own
         # `precision: 16` AMP, hparams_base.yaml:45; BASELINE configs[4]) -- needs peppa_amd.amp.GradScaler around the

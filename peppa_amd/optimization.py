@@ -94,7 +94,7 @@ class BertAdam(Optimizer):
             up = lambda a: torch.from_numpy(a).pin_memory().to(device, non_blocking=True)
             if len(self._chunk_cache) > 256:      # (patterns recur; the cap only guards against unbounded growth)
                 self._chunk_cache.clear()
-            self._chunk_cache[key] = (up(ct), up(co), int(counts.sum()), torch.empty(len(numels), dtype=f32, device=device))
+            self._chunk_cache[key] = (up(ct), up(co), int(counts.sum()), torch.empty(len(numels) + int(counts.sum()), dtype=f32, device=device))   # norms [tensors] + [chunks] (deterministic mode)
         return self._chunk_cache[key]
 
     def step(self, closure=None, skip_flag=None):

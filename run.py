@@ -39,6 +39,9 @@ def main(args):
         if key in config and value is not None:
             config[key] = value
     config['git_commit'] = get_git_commit()
+    if args.deterministic:
+        config.setdefault('mi355x', {})
+        config['mi355x'] = dict(config['mi355x'] or {}, deterministic=True)
     if args.random_init:
         config['video']['pretrained'] = False
         config['audio']['pretrained'] = False
@@ -94,6 +97,8 @@ if __name__ == '__main__':
     parser.add_argument("--random_init", action="store_true",
                         help="pretrained weights cannot be downloaded offline: build the same architectures from random "
                              "init (sets video.pretrained / audio.pretrained to false in the saved config)")
+    parser.add_argument("--deterministic", action="store_true",
+                        help="bitwise-reproducible steps (pp_set_option('deterministic', 1): ordered reductions, slower)")
     parser.add_argument("--frames", type=int, default=16)
     parser.add_argument("--size", type=int, default=112)
     parser.add_argument("--samples", type=int, default=36800)

@@ -481,6 +481,30 @@ def test_data_parallel_machinery_single_rank():
             # gradient (float atomics in the audio statistics perturb dV in the last bits and the trunk amplifies
             # that, DESIGN.md "Numerics"; tools/probe/dp_dbg.py); a mis-ordered pack gives O(1) errors or zeros.
             assert err <= 0.12 * max(p.grad.abs().max().item(), 1e-2 * gmax), f"{n}: {err}"
+        # Deterministic mode: nothing is left to summation order, so the data-parallel path (early hand-off, packing on the
+        # producing streams, RCCL all-reduce over one rank) must reproduce the plain step BIT FOR BIT (the 12 % above is
+        # what float atomics force on the default mode)
+        prev_det = H.set_deterministic(True)
+        try:
+            net.zero_grad(set_to_none=True)
+            loss_a = net.training_step(batch, 0)
+            loss_a.backward()
+            torch.cuda.synchronize()
+            g_plain = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+            os.environ["PEPPA_FORCE_DIST"] = "1"
+            buckets = default_buckets(net, torch.device(DEV))
+            net.zero_grad(set_to_none=True)
+            loss_b = net.training_step(batch, 0)
+            loss_b.backward()
+            buckets.finish()
+            torch.cuda.synchronize()
+            buckets.close()
+            os.environ["PEPPA_FORCE_DIST"] = "0"
+            assert torch.equal(loss_a, loss_b)
+            bad = [n for n, p in net.named_parameters() if p.grad is not None and not torch.equal(p.grad, g_plain[n])]
+            assert not bad, f"deterministic mode: {len(bad)} gradients differ between the plain and the data-parallel step: {bad[:5]}"
+        finally:
+            H.set_deterministic(prev_det)
         # SyncBN option: every BatchNorm layer all-reduces its statistics rows through RCCL (identity with one rank)
         from peppa_amd import layers as PL
         from peppa_amd.dist import enable_sync_bn

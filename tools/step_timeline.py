@@ -46,26 +46,54 @@ def mark(name):
         marks.setdefault(name, []).append(e)
 
 
-ev, ea = net.encode_video, net.encode_audio
+def find_node(fn, name, seen=None):
+    """the autograd node of a tower (VideoTrunkFnBackward / Wav2Vec2FnBackward) below an embedding's grad_fn"""
+    seen = set() if seen is None else seen
+    if fn is None or fn in seen:
+        return None
+    seen.add(fn)
+    if type(fn).__name__.startswith(name):
+        return fn
+    for nxt, _ in fn.next_functions:
+        hit = find_node(nxt, name, seen)
+        if hit is not None:
+            return hit
+    return None
+
+
+ep = net.encode_pair
+
+
+def encode_pair(video, audio):
+    """events around the two forward passes: the trunk is launched first (prelaunch), the audio tower on its own stream"""
+    mark("video_fwd_begin")
+    from peppa_amd import video as PV
+    side = PV.tower_stream(video.device)
+    V, A = ep(video, audio)
+    mark("fwd_joined")                       # trunk stream, after it has waited for the audio stream
+    if ON:
+        with torch.cuda.stream(side):
+            mark("audio_fwd_end")            # audio stream: end of its forward work
+        for emb, name, tag in ((V, "VideoTrunkFn", "video"), (A, "Wav2Vec2Fn", "audio")):
+            node = find_node(emb.grad_fn, name)
+            assert node is not None, name
+            node.register_prehook(lambda g, tag=tag: mark(tag + "_bwd_begin"))
+            node.register_hook(lambda gi, go, tag=tag: mark(tag + "_bwd_end"))
+    return V, A
+
+
+net.encode_pair = encode_pair
+# the trunk's own forward ends where its pooling tail begins: mark inside encode_video (called by encode_pair after the
+# audio tower has been launched; the mark lands on the trunk stream behind the prelaunched trunk)
+ev = net.encode_video
 
 
 def encode_video(x):
-    mark("video_fwd_begin"); out = ev(x); mark("video_fwd_end")
-    if ON and out.grad_fn is not None:
-        out.grad_fn.register_prehook(lambda g: mark("video_bwd_begin"))
-        out.grad_fn.register_hook(lambda gi, go: mark("video_bwd_end"))
-    return out
+    mark("video_trunk_fwd_end")
+    return ev(x)
 
 
-def encode_audio(x):
-    mark("audio_fwd_begin"); out = ea(x); mark("audio_fwd_end")
-    if ON and out.grad_fn is not None:
-        out.grad_fn.register_prehook(lambda g: mark("audio_bwd_begin"))
-        out.grad_fn.register_hook(lambda gi, go: mark("audio_bwd_end"))
-    return out
-
-
-net.encode_video, net.encode_audio = encode_video, encode_audio
+net.encode_video = encode_video
 
 
 def step(i):
@@ -94,8 +122,8 @@ ON = True
 timed = run(args.steps)
 ON = False
 n = args.steps
-names = ["step_begin", "video_fwd_begin", "video_fwd_end", "audio_fwd_begin", "audio_fwd_end", "loss_fwd_end", "video_bwd_begin",
-         "audio_bwd_begin", "video_bwd_end", "audio_bwd_end", "backward_end", "step_end"]
+names = ["step_begin", "video_fwd_begin", "video_trunk_fwd_end", "audio_fwd_end", "fwd_joined", "loss_fwd_end", "video_bwd_begin",
+         "audio_bwd_begin", "audio_bwd_end", "video_bwd_end", "backward_end", "step_end"]
 for k in names:
     assert len(marks.get(k, [])) == n, (k, len(marks.get(k, [])))
 rel = {k: sum(marks["step_begin"][i].elapsed_time(marks[k][i]) for i in range(n)) / n for k in names}
@@ -103,14 +131,16 @@ lines = [f"# Phase timeline of one training step, HIP events on the phases' own 
          f"hparams_base, batch {args.batch}, bf16, {n} steps after {args.warmup} warm-up: {plain:.2f} ms/step without the events, "
          f"{timed:.2f} ms/step with them.  Times in ms after the step's first launch (mean over the steps).", "",
          "| event (stream) | ms |", "|---|---|"]
-stream_of = {"video": "trunk stream", "audio": "audio stream", "loss": "trunk stream", "backward": "trunk stream", "step": "trunk stream"}
+stream_of = {"video": "trunk stream", "audio": "audio stream", "loss": "trunk stream", "backward": "trunk stream", "step": "trunk stream",
+             "fwd": "trunk stream"}
 for k in names:
     lines.append(f"| {k} ({stream_of[k.split('_')[0]]}) | {rel[k]:.2f} |")
 d = lambda a, b: rel[b] - rel[a]
 lines += ["", "| phase | ms | reading |", "|---|---|---|",
-          f"| video forward (trunk stream) | {d('video_fwd_begin', 'video_fwd_end'):.2f} | |",
-          f"| audio forward (audio stream) | {d('audio_fwd_begin', 'audio_fwd_end'):.2f} | starts {rel['audio_fwd_begin'] - rel['video_fwd_begin']:.2f} ms after the video forward |",
-          f"| trunk stream waits for the audio forward, then loss forward + backward | {d('video_fwd_end', 'video_bwd_begin'):.2f} | audio forward ends {rel['audio_fwd_end'] - rel['video_fwd_end']:+.2f} ms relative to the video forward |",
+          f"| video trunk forward (trunk stream) | {d('video_fwd_begin', 'video_trunk_fwd_end'):.2f} | |",
+          f"| audio forward (audio stream, beside it) | {rel['audio_fwd_end'] - rel['video_fwd_begin']:.2f} | ends {rel['audio_fwd_end'] - rel['video_trunk_fwd_end']:+.2f} ms relative to the trunk's forward |",
+          f"| heads, join of the streams, loss forward | {d('video_trunk_fwd_end', 'loss_fwd_end'):.2f} | |",
+          f"| loss backward + heads backward until the towers' backward passes start | {max(rel['video_bwd_begin'], rel['audio_bwd_begin']) - rel['loss_fwd_end']:.2f} | video at {rel['video_bwd_begin']:.2f}, audio at {rel['audio_bwd_begin']:.2f} |",
           f"| video backward (trunk stream; weight gradients included) | {d('video_bwd_begin', 'video_bwd_end'):.2f} | |",
           f"| audio backward (audio stream) | {d('audio_bwd_begin', 'audio_bwd_end'):.2f} | ends {rel['audio_bwd_end'] - rel['video_bwd_end']:+.2f} ms relative to the video backward |",
           f"| end of both backward passes -> optimizer done | {rel['step_end'] - max(rel['video_bwd_end'], rel['audio_bwd_end']):.2f} | BertAdam + its norms |",
