@@ -783,7 +783,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         };
         PP_STAMP(1)
         auto issue_dmas = [&](const int pos) __attribute__((always_inline)) {
-          if (pos >= 0 && pos != (win_wave ? PP_WIN_WPOS : 1)) return;
+          if (pos >= 0 && pos != (win_wave ? PP_WIN_WPOS : (STG ? 0 : 1))) return;   // (STG: the weights have ONE step to land: issue first)
           if (win_wave) {
             if (TW) {
               if (j == 0) {

@@ -9,6 +9,7 @@ mkdir -p $D
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $D/instep -- python3 tools/step_loop.py --steps 6 --launch-log $D/instep_launch.json "$@" > $D/instep.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $D/alone -- python3 tools/step_loop.py --steps 6 --isolated --launch-log $D/alone_launch.json "$@" > $D/alone.log 2>&1
+if [ -n "$SKIP_PMC" ]; then tail -n 1 $D/instep.log $D/alone.log; exit 0; fi
 rocprofv3 -L > $D/counters.txt 2>&1 || true
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D/pmc_sq -- python3 tools/step_loop.py --steps 2 --warmup 1 --isolated --launch-log $D/pmc_launch.json "$@" > $D/pmc_sq.log 2>&1
-tail -1 $D/instep.log $D/alone.log $D/pmc_sq.log
+tail -n 1 $D/instep.log $D/alone.log $D/pmc_sq.log

@@ -22,6 +22,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--out", default=None)
+ap.add_argument("--video-only", action="store_true", help="the video tower alone (audio embeddings = constants): its forward / backward durations without the audio tower beside them")
 args = ap.parse_args()
 
 import pig.models
@@ -94,6 +95,31 @@ def encode_video(x):
 
 
 net.encode_video = encode_video
+
+
+if args.video_only:
+    A_const = torch.nn.functional.normalize(torch.randn(args.batch, 512, device="cuda"), dim=1)
+
+    def encode_pair_v(video, audio):
+        mark("video_fwd_begin")
+        from peppa_amd import video as PV
+        video2 = pig.models.prelaunch_video_trunk(net.video_encoder, video)
+        net.video_encoder._paired = True
+        try:
+            V = encode_video(video2)
+        finally:
+            net.video_encoder._paired = False
+        mark("fwd_joined")
+        if ON:
+            mark("audio_fwd_end")
+            node = find_node(V.grad_fn, "VideoTrunkFn")
+            def pre(g):
+                mark("video_bwd_begin"); mark("audio_bwd_begin"); mark("audio_bwd_end")
+            node.register_prehook(pre)
+            node.register_hook(lambda gi, go: mark("video_bwd_end"))
+        return V, A_const
+
+    net.encode_pair = encode_pair_v
 
 
 def step(i):
