@@ -104,6 +104,11 @@ def main():
         from peppa_amd.launch import require_devices, spawn_ranks
         require_devices(args.gpus)
         sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    # stdout carries exactly ONE line, the JSON record: libraries that print banners there (RCCL's version block when
+    # NCCL_DEBUG=VERSION is set in the environment) go to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -211,7 +216,7 @@ def main():
         ach = flops / secs / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/), when this family was profiled
         try:
-            for fn in ("r02_traffic.json", "r01_traffic.json"):
+            for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
                 path = os.path.join(ROOT, "profiles", fn)
                 if traffic is None and os.path.exists(path):
                     traffic = json.load(open(path)).get(name)
@@ -277,7 +282,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, args)
         except Exception as e:  # report, never hide
             out["cpu_baseline"] = {"error": repr(e)}
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

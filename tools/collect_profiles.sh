@@ -12,4 +12,8 @@ rocprofv3 --kernel-trace --output-format csv -d $D/alone -- python3 tools/step_l
 if [ -n "$SKIP_PMC" ]; then tail -n 1 $D/instep.log $D/alone.log; exit 0; fi
 rocprofv3 -L > $D/counters.txt 2>&1 || true
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D/pmc_sq -- python3 tools/step_loop.py --steps 2 --warmup 1 --isolated --launch-log $D/pmc_launch.json "$@" > $D/pmc_sq.log 2>&1
+if [ -n "$TRAFFIC" ]; then   # HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes (together they exceed the TCC slots)
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/pmc_fetch -- python3 tools/step_loop.py --steps 2 --warmup 1 --isolated --launch-log $D/traffic_launch.json "$@" > $D/pmc_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/pmc_write -- python3 tools/step_loop.py --steps 2 --warmup 1 --isolated "$@" > $D/pmc_write.log 2>&1
+fi
 tail -n 1 $D/instep.log $D/alone.log $D/pmc_sq.log

@@ -12,7 +12,7 @@ FAMILIES = [
     ("generic / ring implicit GEMM (igemm)", r"igemm_kernel"),
     ("sliding-window wgrad (wgrad_sw)", r"wgrad_sw_kernel"),
     ("temporal-window wgrad (wgrad_tw)", r"wgrad_tw_kernel"),
-    ("generic wgrad", r"wgrad_kernel"),
+    ("generic wgrad (incl. grouped)", r"wgrad_kernel|wgrad_slab"),
     ("BatchNorm apply", r"bn_apply_kernel"),
     ("BatchNorm backward reduce", r"bn_bwd_reduce_kernel"),
     ("BatchNorm backward apply", r"bn_bwd_apply_kernel"),
@@ -30,9 +30,22 @@ FAMILIES = [
 ]
 
 
+def rows_of(path):
+    """kernel_stats.csv rows (Name, Calls, TotalDurationNs), or the same aggregated from a kernel_trace.csv"""
+    rows = list(csv.DictReader(open(path)))
+    if rows and "Kernel_Name" in rows[0]:
+        agg = {}
+        for r in rows:
+            a = agg.setdefault(r["Kernel_Name"], [0, 0])
+            a[0] += 1
+            a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        return [{"Name": k, "Calls": c, "TotalDurationNs": ns} for k, (c, ns) in agg.items()]
+    return rows
+
+
 def load(path, steps):
     fam = {}
-    for r in csv.DictReader(open(path)):
+    for r in rows_of(path):
         name = r["Name"]
         for label, pat in FAMILIES:
             if re.search(pat, name):
