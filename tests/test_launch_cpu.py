@@ -63,8 +63,8 @@ def test_bench_starts_its_own_ranks_two_ranks_sharing_one_gpu():
                         "--batch", "4", "--frames", "8", "--size", "64", "--samples", "16000", "--no-cpu-baseline"],
                        env=_env(PEPPA_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-500:]      # stdout = the record, nothing else (no library banners)
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"].startswith("dp2")
     assert rec["value"] > 0
