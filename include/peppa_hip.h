@@ -342,6 +342,11 @@ int pp_triplet_loss_fwd(const float* V, const float* A, int N, int D, float marg
 /* dV, dA fp32 [N][D] = dloss * dL/dV, dL/dA (dloss read from device memory) */
 int pp_triplet_loss_bwd(const float* V, const float* A, int N, int D, const float* dloss, const void* ws,
                         float* dV, float* dA, pp_stream_t s);
+/* OPT-IN extension, not in the reference (its loss sums all negatives: pig/loss.py:41-48): in-batch hardest-negative
+ * mining -- loss = (1/N) sum_i [relu(m + max_{j != i} S_ij - S_ii) + relu(m + max_{j != i} S_ji - S_ii)], the maxima by a
+ * wavefront-64 arg-max.  Same workspace as pp_triplet_loss_fwd; the backward pass is pp_triplet_loss_bwd. */
+int pp_triplet_loss_hardest_fwd(const float* V, const float* A, int N, int D, float margin, float* loss, void* ws,
+                                size_t ws_bytes, pp_stream_t s);
 
 /* pig/loss.py:51-55 cosine_matrix(U, V): out [Nu][Nv]; ws (Nu+Nv)*D floats */
 int pp_cosine_matrix(const float* U, const float* V, int Nu, int Nv, int D, float* out, float* ws, pp_stream_t s);

@@ -171,13 +171,27 @@ def contrastive(S, margin=0.2):
     return ((col + row) * off).sum() / n ** 2
 
 
+def contrastive_hardest(S, margin=0.2):
+    """Opt-in extension (NOT pig/loss.py): per anchor only the hardest in-batch negative, both directions, mean over N.
+    Checker for pp_triplet_loss_hardest_fwd."""
+    N = S.shape[0]
+    d = torch.diag(S)
+    if N == 1:
+        return S.sum() * 0.0
+    off = S.masked_fill(torch.eye(N, dtype=torch.bool, device=S.device), float("-inf"))
+    hr = off.max(dim=1).values          # video i against its hardest audio negative
+    hc = off.max(dim=0).values          # audio j against its hardest video negative
+    return (torch.relu(margin + hr - d) + torch.relu(margin + hc - d)).sum() / N
+
+
 class TripletLoss(nn.Module):
-    def __init__(self, margin):
+    def __init__(self, margin, hardest=False):
         super().__init__()
-        self.margin = margin
+        self.margin, self.hardest = margin, hardest
 
     def forward(self, Vv, Aa):
-        return contrastive(cosine_matrix(Vv, Aa), self.margin)
+        S = cosine_matrix(Vv, Aa)
+        return contrastive_hardest(S, self.margin) if self.hardest else contrastive(S, self.margin)
 
 
 def triplet_accuracy(anchor, positive, negative, dim=1, discrete=True):

@@ -127,6 +127,7 @@ SIGNATURES = {
     "pp_attnpool_ws_floats": [I, I, I, I, I],
     "pp_triplet_workspace_bytes": [I, I],
     "pp_triplet_loss_fwd": [P, P, I, I, F, P, P, Z, P],
+    "pp_triplet_loss_hardest_fwd": [P, P, I, I, F, P, P, Z, P],
     "pp_triplet_loss_bwd": [P, P, I, I, P, P, P, P, P],
     "pp_recall_at_n": [P, I, I, I, P, I, I, P, I, P, P],
     "pp_cosine_matrix": [P, P, I, I, I, P, P, P],

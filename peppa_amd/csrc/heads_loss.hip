@@ -397,6 +397,55 @@ __global__ void loss_sum_kernel(const float* __restrict__ partials, int n, float
     loss[0] = s;
   }
 }
+// ---- opt-in extension (NOT in the reference, whose loss sums ALL negatives: pig/loss.py:41-48): in-batch
+// hardest-negative mining.  loss = (1/N) sum_i [ relu(m + max_{j != i} S_ij - S_ii) + relu(m + max_{j != i} S_ji - S_ii) ].
+// One workgroup per (anchor i, side): lane-parallel scores against every candidate j, then a wavefront-64 arg-max
+// butterfly ((value, index) pairs through ds-free lane shuffles; ties go to the smaller index), the four waves meet in LDS.
+// The winner's coefficient 1/N is scattered into the dense G of the all-negatives path (at most two adders per entry, both
+// adding the same value: order-independent) and rowc / colc carry N x "hinge active", so that pp_triplet_loss_bwd runs
+// unchanged: its diagonal term -(rowc + colc) / N^2 becomes -(active_r + active_c) / N.
+__global__ __launch_bounds__(256) void hardest_kernel(const LossWs w, int N, int D, float margin, float* __restrict__ partials) {
+  extern __shared__ float anchor[];          // D floats, then 4 x (value, index)
+  float* wbest = anchor + D;
+  const int i = blockIdx.x, side = blockIdx.y;
+  const float* arow = (side ? w.An : w.Vn) + (long long)i * D;
+  const float* cand = side ? w.Vn : w.An;
+  for (int d = threadIdx.x; d < D; d += 256) anchor[d] = arow[d];
+  __syncthreads();
+  float best = -3.0e38f;
+  int bidx = 0x7fffffff;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    if (j == i) continue;
+    const float* c = cand + (long long)j * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += anchor[d] * c[d];
+    if (s > best) { best = s; bidx = j; }          // j increases: a tie keeps the smaller index
+  }
+  // wavefront-64 arg-max: butterfly over (value, index); equal values -> smaller index, so every lane ends with the same pair
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bidx, off);
+    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { wbest[2 * wave] = best; wbest[2 * wave + 1] = __int_as_float(bidx); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      const float ov = wbest[2 * k];
+      const int oi = __float_as_int(wbest[2 * k + 1]);
+      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    const float invn = 1.f / (float)N;
+    float h = 0.f;
+    if (N > 1) h = margin + best - w.diag[i];
+    const bool active = N > 1 && h > 0.f;
+    if (active) atomicAdd(w.G + (side ? (long long)bidx * N + i : (long long)i * N + bidx), invn);
+    (side ? w.colc : w.rowc)[i] = active ? (float)N : 0.f;
+    partials[side * N + i] = active ? h * invn : 0.f;
+  }
+}
 __global__ void scale_f32_kernel(float* x, const float* sc, long long n) {
   const float k = sc[0];
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= k;
@@ -498,6 +547,20 @@ extern "C" int pp_triplet_loss_fwd(const float* V, const float* A, int N, int D,
   float* const partials = (pp_opt_deterministic && (size_t)nt * nt <= (size_t)N * D) ? w.dVn : nullptr;
   hipLaunchKernelGGL(loss_tile_kernel, dim3(nt, nt), dim3(256), 0, S_, w, (const float*)w.diag, loss, N, D, margin, partials);
   if (partials) hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, S_, (const float*)partials, nt * nt, loss);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+/* Opt-in hardest-negative variant of pp_triplet_loss_fwd (same workspace, same backward entry: pp_triplet_loss_bwd). */
+extern "C" int pp_triplet_loss_hardest_fwd(const float* V, const float* A, int N, int D, float margin, float* loss, void* ws,
+                                           size_t ws_bytes, pp_stream_t s) {
+  PP_CHECK_ARG(N > 0 && D > 0 && V && A && loss && ws, "pp_triplet_loss_hardest_fwd: bad arguments");
+  PP_CHECK_ARG(ws_bytes >= pp_triplet_workspace_bytes(N, D) && (size_t)2 * N <= (size_t)N * D, "pp_triplet_loss_hardest_fwd: workspace too small");
+  const LossWs w = loss_ws(ws, N, D);
+  hipLaunchKernelGGL(loss_prep_kernel, dim3(N), dim3(256), 0, S_, V, A, w, loss, D);
+  if (hipMemsetAsync(w.G, 0, (size_t)N * N * 4, S_) != hipSuccess) { pp_set_error("pp_triplet_loss_hardest_fwd: memset"); return PP_ERR_HIP; }
+  hipLaunchKernelGGL(hardest_kernel, dim3(N, 2), dim3(256), (size_t)(D + 8) * 4, S_, w, N, D, margin, w.dVn);
+  hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, S_, (const float*)w.dVn, 2 * N, loss);     // ordered: bitwise reproducible
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

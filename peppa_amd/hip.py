@@ -514,6 +514,12 @@ def triplet_loss_fwd(V, A, margin, loss, ws):
          _s())
 
 
+def triplet_loss_hardest_fwd(V, A, margin, loss, ws):
+    N, D = V.shape
+    call("pp_triplet_loss_hardest_fwd", _p(V, f32), _p(A, f32), N, D, margin, _p(loss, f32), _p(ws), ws.numel() * ws.element_size(),
+         _s())
+
+
 def triplet_loss_bwd(V, A, dloss, ws, dV, dA):
     N, D = V.shape
     call("pp_triplet_loss_bwd", _p(V, f32), _p(A, f32), N, D, _p(dloss, f32), _p(ws), _p(dV, f32), _p(dA, f32), _s())

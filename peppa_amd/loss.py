@@ -9,14 +9,14 @@ from .hip import f32
 
 class TripletLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, V, A, margin):
+    def forward(ctx, V, A, margin, hardest=False):
         if not (V.is_cuda and A.is_cuda):
             raise H.PeppaHipError("peppa_amd.loss needs CUDA/HIP tensors (no CPU fallback)")
         V, A = V.contiguous().float(), A.contiguous().float()
         N, D = V.shape
         ws = torch.empty(H.triplet_workspace_bytes(N, D) // 4, dtype=f32, device=V.device)
         loss = torch.empty(1, dtype=f32, device=V.device)
-        H.triplet_loss_fwd(V, A, float(margin), loss, ws)
+        (H.triplet_loss_hardest_fwd if hardest else H.triplet_loss_fwd)(V, A, float(margin), loss, ws)
         ctx.save_for_backward(V, A, ws)
         return loss.reshape(())
 
@@ -25,17 +25,23 @@ class TripletLossFn(torch.autograd.Function):
         V, A, ws = ctx.saved_tensors
         dV, dA = torch.empty_like(V), torch.empty_like(A)
         H.triplet_loss_bwd(V, A, dloss.reshape(1).contiguous().float(), ws, dV, dA)
-        return dV, dA, None
+        return dV, dA, None, None
 
 
 class TripletLoss(torch.nn.Module):
-    def __init__(self, margin):
+    """`TripletLoss(margin)` is the reference's loss (pig/loss.py:28-39): the hinge summed over ALL in-batch negatives.
+    `hardest=True` is an opt-in extension that is NOT in the reference (yaml `mi355x: {hardest_negatives:
+    true}`): per anchor only its hardest in-batch negative counts, found by a wavefront-64 arg-max
+    (pp_triplet_loss_hardest_fwd): (1/N) sum_i [relu(m + max_{j != i} S_ij - S_ii) + relu(m + max_{j != i} S_ji - S_ii)]."""
+
+    def __init__(self, margin, hardest=False):
         super(TripletLoss, self).__init__()
         self.margin = margin
+        self.hardest = bool(hardest)
 
     def forward(self, V, A):
         """V, A: (N, D) embeddings (video, audio) -> scalar loss."""
-        return TripletLossFn.apply(V, A, self.margin)
+        return TripletLossFn.apply(V, A, self.margin, self.hardest)
 
 
 class CosineMatrixFn(torch.autograd.Function):

@@ -415,7 +415,9 @@ class PeppaPig(_Base):
         self.config = config
         if pl is not None:
             self.save_hyperparameters(config)
-        self.loss = TripletLoss(margin=self.config['margin'])
+        # (`mi355x: {hardest_negatives: true}`: opt-in hardest-negative mining, an extension; the reference sums all negatives)
+        self.loss = TripletLoss(margin=self.config['margin'],
+                                hardest=bool((config.get('mi355x', {}) or {}).get('hardest_negatives', False)))
         static = self.config['video'].get('static', False)
         video_config = {key: value for key, value in self.config['video'].items() if key != 'static'}
         extra = config.get('mi355x', {}) or {}     # optional block the reference ignores: local pretrained weights

@@ -258,6 +258,38 @@ def test_grouped_linear_wgrad_matches_torch_and_is_bitwise_reproducible(M, N, K,
             assert torch.equal(dw, dw0) and torch.equal(db, db0), rep
 
 
+@pytest.mark.parametrize("N", [1, 4, 37, 64, 512])
+def test_hardest_negative_loss_opt_in(N):
+    """Opt-in extension (BASELINE north_star: "in-batch hardest-negative mining with wavefront-64 argmin"; the REFERENCE has none,
+    SURVEY 0.1, and the default stays its all-negatives sum): value and both gradients against the oracle's autograd, fp32
+    tolerances; a tie goes to the smaller index; the default TripletLoss is untouched."""
+    import pig.loss
+    from oracle import model as O
+    g = torch.Generator().manual_seed(N)
+    V = torch.randn(N, 512, generator=g).requires_grad_()
+    A = (0.25 * V.detach() + torch.randn(N, 512, generator=g)).requires_grad_()      # (correlated pairs: some hinges off for large N)
+    ref = O.TripletLoss(0.2, hardest=True)(V, A)
+    ref.backward()
+    Vd, Ad = V.detach().to(DEV).requires_grad_(), A.detach().to(DEV).requires_grad_()
+    loss = pig.loss.TripletLoss(0.2, hardest=True)(Vd, Ad)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) <= 1e-6, (loss.item(), ref.item())
+    for got, want in ((Vd.grad, V.grad), (Ad.grad, A.grad)):
+        assert (got.cpu() - want).abs().max().item() <= 1e-6 + 1e-5 * want.abs().max().item()
+    if N >= 4:
+        assert loss.item() > 0 and not torch.equal(loss.detach().cpu(), pig.loss.TripletLoss(0.2)(Vd, Ad).detach().cpu())
+        assert abs(pig.loss.TripletLoss(0.2)(Vd, Ad).item() - O.TripletLoss(0.2)(V, A).item()) <= 1e-6       # default unchanged
+    if N == 4:      # exact tie: audio 1 and 2 identical -> video 0's hardest negative is index 1 (the smaller)
+        A2 = A.detach().clone()
+        A2[2] = A2[1]
+        Vt, At = V.detach().to(DEV).requires_grad_(), A2.to(DEV).requires_grad_()
+        pig.loss.TripletLoss(5.0, hardest=True)(Vt, At).backward()
+        Vr, Ar = V.detach().clone().requires_grad_(), A2.clone().requires_grad_()
+        O.TripletLoss(5.0, hardest=True)(Vr, Ar).backward()          # torch.max returns the first maximal index as well
+        assert (Vt.grad.cpu() - Vr.grad).abs().max().item() <= 1e-5 * Vr.grad.abs().max().item() + 1e-6
+
+
 def test_batched_attention_gemms():
     """Q K^T per (batch, head) with strided operands, softmax, and the per-head transpose."""
     g = torch.Generator().manual_seed(4)
