@@ -1057,6 +1057,8 @@ def test_bn_backward_sums_in_the_dgrad_epilogue(case, tall):
     (288, 128, 1, 4, 9, 10),      # two channel blocks, ragged 64-position blocks (90 positions per frame)
     (230, 128, 2, 3, 5, 5),       # 240 padded channels: second channel block partly empty; frames smaller than a block
     (576, 256, 1, 2, 7, 7),       # two row blocks of dW, T = 2 (every step has a tap outside the clip)
+    (45, 64, 2, 9, 9, 10),        # the stem's width: the narrow form (48-channel blocks, six steps of look-ahead), ragged blocks
+    (48, 64, 1, 3, 8, 8),         # narrow form, a clip shorter than the look-ahead
 ])
 def test_temporal_window_wgrad_matches_generic(case):
     """Temporal sliding-window weight gradient (X blocks of frames t-1, t, t+1 kept in an LDS ring while a 64-position
