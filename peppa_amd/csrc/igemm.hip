@@ -21,6 +21,8 @@ int pp_opt_win_tall = 1;       // window kernel: 512-row tiles (four row tiles p
 int pp_opt_deterministic = 0;   // ordered reductions instead of fp32 atomics wherever a sum crosses workgroups (slower; see the header)
 int pp_opt_tw_producers = 1;   // temporal sliding-window weight gradient: three extra waves issue the LDS-DMAs, the nine multiplying waves none
 int pp_opt_tw_narrow = 1;      // temporal sliding-window weight gradient: 48-channel blocks with a deep look-ahead for cg <= 48
+int pp_opt_ln_bwd_alone = -1;   // LayerNorm backward keeps LDS-using kernels off its CUs (-1: in deterministic mode, 0 / 1: never / always)
+int pp_opt_win_producers = 1;  // window kernel, spatial form: four extra waves issue the LDS-DMAs (1: tiles up to 128 columns, 2: all, 0: never)
 int pp_opt_win_stagger = 0;    // window kernel, spatial form: waves 4-7 request their fragments ahead of the K-step's barrier
 int pp_opt_win_temporal = 1;   // window kernel also for (3,1,1) stride-1 convs (frames-by-positions tiles)
 int pp_opt_win_igemm = 1024;   // window kernel for (1,3,3) stride-1 convs (forward / data gradient) once M >= this (0 = never)
@@ -50,6 +52,8 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "deterministic")) { pp_opt_deterministic = value ? 1 : 0; return PP_OK; }
   if (!strcmp(name, "tw_producers")) { pp_opt_tw_producers = value; return PP_OK; }
   if (!strcmp(name, "tw_narrow")) { pp_opt_tw_narrow = value; return PP_OK; }
+  if (!strcmp(name, "ln_bwd_alone")) { pp_opt_ln_bwd_alone = value; return PP_OK; }
+  if (!strcmp(name, "win_producers")) { pp_opt_win_producers = value; return PP_OK; }
   if (!strcmp(name, "win_stagger")) { pp_opt_win_stagger = value; return PP_OK; }
   if (!strcmp(name, "win_igemm")) { pp_opt_win_igemm = value; return PP_OK; }
   if (!strcmp(name, "win_temporal")) { pp_opt_win_temporal = value; return PP_OK; }

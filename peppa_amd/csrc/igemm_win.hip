@@ -23,6 +23,7 @@ extern int pp_opt_win_out_nt;
 extern int pp_opt_persist_cus;
 extern int pp_opt_win_igemm;
 extern int pp_opt_win_stagger;
+extern int pp_opt_win_producers;
 
 // Timing ablations for tools/probe/win_ablate.py (results are WRONG with any bit set; the shipped library has 0):
 // 1 weights only for a workgroup's first tile, 2 windows likewise, 4 no fragment reads / MFMAs, 8 no epilogue,
@@ -129,8 +130,11 @@ struct WinArgs {
 // output as its dz: the tile is in registers / LDS anyway, so bn_bwd_reduce's pass over dz (2 B per element of HBM
 // traffic, a launch) disappears; its read of y moves here.
 // STG = staggered halves (spatial form, three weight slots): see the K-step below.
-template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false, bool STG = false>
-__global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
+// PROD = four producer waves (8, 9: weights; 10, 11: windows) issue every LDS-DMA and do nothing else; the eight
+// multiplying waves issue none and never wait on vmcnt (wgrad_tw.hip measured why: a wave that multiplies is not at its
+// DMA instructions when the memory pipeline has room for them).  Twelve waves = three per SIMD = 168 registers each.
+template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false, bool STG = false, bool PROD = false>
+__global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap, const int out_nt) {
   constexpr int BM = 16 * MT * NW;
   // temporal tiles with narrow outputs: no halo rows at all and THREE window buffers -- the window of the phase after
@@ -150,7 +154,9 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   // and wait for them step by step; waves 4..7 issue only window pieces -- the WHOLE next window at the start of a
   // phase -- and wait for them once per phase, so a full window (40-70 KB per CU) is in flight under the phase's
   // matrix work instead of the one or two pieces a per-step wait allows.  All eight waves multiply.
-  constexpr int NWW = NW / 2;                                 // waves per role
+  constexpr int NPW = 2;                                      // producer waves per role (PROD)
+  constexpr int NWW = PROD ? NPW : NW / 2;                    // waves per role
+  static_assert(!PROD || (!TW && !BNR && !BNA && !STG), "producer waves: spatial form, plain epilogue");
   constexpr int NWP = (WPIECES + NWW - 1) / NWW;              // window pieces per window wave and phase
   constexpr int NBI = (BN + 8 * NWW - 1) / (8 * NWW);         // weight pieces per weight wave and K-step (last one maybe absent)
   constexpr int NTAP = TW ? 3 : 9;
@@ -174,8 +180,12 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool win_wave = wave >= NWW;                          // role (wave-uniform)
-  const int rwave = win_wave ? wave - NWW : wave;             // index inside the role
+  // roles (wave-uniform)
+  const bool is_comp = !PROD || wave < NW;
+  const bool win_wave = PROD ? wave >= NW + NPW : wave >= NWW;
+  const bool wgt_wave = PROD ? (wave >= NW && wave < NW + NPW) : wave < NWW;
+  const int rwave = PROD ? (win_wave ? wave - NW - NPW : (wgt_wave ? wave - NW : 0))   // index inside the role
+                         : (win_wave ? wave - NWW : wave);
   const int fr = lane & 15, fq = lane >> 4;
   const int G = gridDim.x, bid = blockIdx.x;
   auto tile_index = [&](int it) __attribute__((always_inline)) -> int {   // persistent walk, XCD-contiguous (igemm.hip)
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   // coinciding.  What that needs: the weights of step s + 1 have landed when the barrier of step s opens (the weight waves
   // wait for ALL their DMAs, not for all but the youngest batch), and a phase's first K-step stays in lockstep (its window
   // is published by that step's barrier).
-  auto compute = [&](const int j, const unsigned char* win, const unsigned char* bslot, auto issue_dmas, auto sync, const bool early) __attribute__((always_inline)) {
+  auto compute = [&](auto comp_c, const int j, const unsigned char* win, const unsigned char* bslot, auto issue_dmas, auto sync, const bool early) __attribute__((always_inline)) {
     // every fragment of the K-step is requested before the first MFMA: written as "load one weight fragment, use it"
     // hipcc keeps ONE fragment register and waits lgkmcnt(0) before every MFMA pair, i.e. one exposed LDS round trip
     // (~100 cycles) per 32 cycles of matrix work
@@ -370,6 +380,11 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
     // the 72 accumulators without spilling).
     constexpr bool REUSE_B = WN >= 8;
     h16x8 af[2][MT], bfm[REUSE_B ? 1 : 2][WN];
+    if constexpr (!decltype(comp_c)::value) {       // producer wave: this K-step's wait, barrier and DMAs
+      sync();
+      issue_dmas(-1);
+      return;
+    }
     if (ABL & 4) {
       sync();
       issue_dmas(-1);
@@ -380,7 +395,12 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       issue_dmas(0);
     }
     const unsigned wbase = (unsigned)(uintptr_t)(lds_ptr)win;
-    const unsigned bbase = (unsigned)(uintptr_t)(lds_ptr)bslot + bfr0;
+    // (laundered: otherwise hipcc prepares the 2 x WN fragment addresses of every ring slot once per workgroup -- 54
+    // registers that spill under the producer form's 168-register budget -- instead of two bases + immediate offsets)
+    unsigned bbase = (unsigned)(uintptr_t)(lds_ptr)bslot + bfr0;
+    asm volatile("" : "+v"(bbase));
+    unsigned bbase1 = bbase ^ 64u;
+    asm volatile("" : "+v"(bbase1));
     auto load_a = [&](const int ks) __attribute__((always_inline)) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       }
     };
     auto load_b = [&](const int ks, const int jn) __attribute__((always_inline)) -> h16x8 {
-      return *(const h16x8*)(lds_ptr)(uintptr_t)((bbase ^ (unsigned)(ks * 64)) + jn * 2048);
+      return *(const h16x8*)(lds_ptr)(uintptr_t)((ks ? bbase1 : bbase) + jn * 2048);
     };
     load_a(0);
 #pragma unroll
@@ -644,6 +664,12 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   //   NBS - 1 ahead and a share of the window of the phase D ahead; multiply.  The K-steps of a chunk are unrolled: which
   //   pieces, which tap, which fragment offsets are compile-time, and a K-step costs its MFMAs, its fragment reads and a
   //   few dozen other instructions (it used to cost several hundred: cursors, divisions and a switch per piece).
+  // The loop is instantiated per role (PROD): the multiplying waves' copy holds no DMA tables and never touches vmcnt, the
+  // producers' copy no accumulators or fragments -- as ONE body the two sets of registers were live together and the
+  // 168-register budget of twelve waves spilled.  Without PROD there is one copy and every wave plays both parts.
+  auto main_loop = [&](auto comp_c) __attribute__((always_inline)) {
+  constexpr bool COMP = decltype(comp_c)::value;
+  constexpr bool DMA = !PROD || !COMP;
   int it = 0;
   int tile = tile_index(0);
   if (tile < 0) return;
@@ -666,7 +692,8 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   constexpr int LA = RW ? 0 : NBS - 1;                          // weight K-steps in flight ahead of the multiply
   constexpr int PPK = TW ? NWP : (NWP + NKC - 1) / NKC;       // window pieces per window wave and K-step
   int last_win = 0;                   // window pieces this (window) wave issued at the previous phase start
-  if (win_wave) {
+  if (!DMA) {
+  } else if (win_wave) {
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       unsigned sb = 0;
@@ -677,6 +704,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         last_win = npieces;
       }
     }
+  } else if (!wgt_wave) {
   } else if (RW) {
     for (int c = 0; c < nchunk; ++c)      // (the launcher checked S <= NBS; same N block for every tile)
 #pragma unroll
@@ -707,27 +735,30 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   };
   auto next_slot = [&](int sl) __attribute__((always_inline)) { return sl + 1 == NBS ? 0 : sl + 1; };
   while (true) {
+    if constexpr (COMP) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     const int next_tile = tile_index(it + 1);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
       unsigned char* const win = smem + wsel * WIN_BYTES;
       unsigned char* const nwin = smem + (wsel + D >= NWIN ? wsel + D - NWIN : wsel + D) * WIN_BYTES;   // of the phase D ahead
       unsigned nbase = 0;
-      const bool nvalid = win_wave && phase_ahead(it, chunk, D, tile, nbase);
+      const bool nvalid = DMA && win_wave && phase_ahead(it, chunk, D, tile, nbase);
 #pragma unroll
       for (int j = 0; j < NKC; ++j) {
         // weight waves, three slots: everything but the batch of the previous iteration (the weights of step s + 1) must
         // have landed; two slots: that batch IS the weights of this step.  Window waves: this phase's window, issued at
         // the start of the previous phase, must have landed when the phase starts; nothing to wait for inside a phase.
         auto sync = [&]() __attribute__((always_inline)) {
-        if (win_wave) {
+        if (!DMA) {
+        } else if (win_wave) {
           // this phase's window has landed once only the younger one (D = 2) is still in flight; a tile's first phase
           // also waits for the epilogue's stores, which sit between them in the counter
           if (j == 0) wait_vmcnt_dyn((drain || D == 1) ? 0 : last_win);
-        } else {
+        } else if (wgt_wave) {
           wait_vmcnt_dyn((drain || NBS == 2 || RW || STG) ? 0 : last_batch);
         }
         drain = false;
@@ -784,7 +815,8 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
         PP_STAMP(1)
         auto issue_dmas = [&](const int pos) __attribute__((always_inline)) {
           if (pos >= 0 && pos != (win_wave ? PP_WIN_WPOS : (STG ? 0 : 1))) return;   // (STG: the weights have ONE step to land: issue first)
-          if (win_wave) {
+          if (!DMA) {
+          } else if (win_wave) {
             if (TW) {
               if (j == 0) {
                 last_win = 0;
@@ -799,7 +831,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
               for (int k = 0; k < NWP; ++k)
                 if (k >= j * PPK && k < (j + 1) * PPK) dma_window_piece(k, nwin, nbase);
             }
-          } else if (!RW) {
+          } else if (wgt_wave && !RW) {
             // the K-step LA ahead: (chunk, j + LA), or the first ones of the next chunk
             const int j2 = j + LA < NKC ? j + LA : j + LA - NKC;
             const int c2 = j + LA < NKC ? chunk : chunk + 1;
@@ -811,7 +843,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
           }
         };
         PP_STAMP(2)
-        compute(j, win, bring + (RW ? chunk * NKC + j : bsl) * B_BYTES, issue_dmas, sync, STG && win_wave && j > 0);
+        compute(comp_c, j, win, bring + (RW ? chunk * NKC + j : bsl) * B_BYTES, issue_dmas, sync, STG && win_wave && j > 0);
         PP_STAMP(3)
         bsl = next_slot(bsl);
       }
@@ -827,7 +859,7 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       setup_tile(next_tile);
       // (two slots: the slot just consumed holds the statistics during the epilogue, so only the other one is refilled:
       // it is the slot of step 0 of the next tile because bsl already points past the consumed one)
-      if (!win_wave && !RW) {
+      if (DMA && wgt_wave && !RW) {
         int sl = bsl;
 #pragma unroll
         for (int a = 0; a < LA; ++a) {
@@ -837,7 +869,11 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
       }
     }
     PP_STAMP(4)
-    if (!(ABL & 8)) epilogue(mb_done, nb_done, ebuf, sbuf);
+    if constexpr (COMP) {
+      if (!(ABL & 8)) epilogue(mb_done, nb_done, ebuf, sbuf);
+    } else if (MT == 2 && p.colstats) {
+      __builtin_amdgcn_s_barrier();     // (the statistics' barrier inside the epilogue)
+    }
     PP_STAMP(5)
     abl_first = false;
     if (next_tile < 0) break;
@@ -850,6 +886,13 @@ __global__ __launch_bounds__(NT, 1) void igemm_win_kernel(const WinArgs p, const
   if (lane == 0 && bid < 256)
     for (int i = 0; i < 8; ++i) pp_win_stamp_buf[(bid * 8 + wave) * 8 + i] = tsum[i];
 #endif
+  };
+  if constexpr (PROD) {
+    if (is_comp) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+  } else {
+    main_loop(std::true_type{});
+  }
 }
 
 // (WN, CC, MT, TW) combinations the data gradients of r2plus1d_18 / r3d_18 / mc3_18 / resnet18 dispatch to get the BNR form
@@ -890,6 +933,17 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
+  if constexpr (!TW) {
+    // (1: where it pays -- tiles up to 128 columns; 144-column tiles keep 72 accumulators + 36 weight-fragment registers
+    // and lose more to the 168-register budget than the producers give back: layer-1 forward 765 -> 845 us; 2: always)
+    if ((pp_opt_win_producers == 2 || (pp_opt_win_producers == 1 && WN <= 8)) && !bna && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {
+      dim3 pblock(NT + 256);
+      if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, true>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+      else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, true>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+      PP_LAUNCH_CHECK();
+      return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
+    }
+  }
   if constexpr (bnr_built<WN, CC, MT, TW>()) {
     if (d.bnr_partials) {
       if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
