@@ -156,7 +156,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   // matrix work instead of the one or two pieces a per-step wait allows.  All eight waves multiply.
   constexpr int NPW = 2;                                      // producer waves per role (PROD)
   constexpr int NWW = PROD ? NPW : NW / 2;                    // waves per role
-  static_assert(!PROD || (!TW && !BNR && !BNA && !STG), "producer waves: spatial form, plain epilogue");
+  static_assert(!PROD || (!BNR && !STG), "producer waves: plain epilogue");
   constexpr int NWP = (WPIECES + NWW - 1) / NWW;              // window pieces per window wave and phase
   constexpr int NBI = (BN + 8 * NWW - 1) / (8 * NWW);         // weight pieces per weight wave and K-step (last one maybe absent)
   constexpr int NTAP = TW ? 3 : 9;
@@ -764,7 +764,9 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         drain = false;
         PP_STAMP(0)
         if (!RW || j == 0) __builtin_amdgcn_s_barrier();
-        if (BNA && j == 0) {
+        if (BNA && j == 0 && !COMP) {        // (producer waves: only the pass's closing barrier)
+          __builtin_amdgcn_s_barrier();
+        } else if (BNA && j == 0) {
           // z = relu(y * scale + shift) on the window that has just landed: 256 rows x six 8-channel octets, three per
           // thread; then every wave sees the activated rows (the masked taps' zero row is the conv's zero padding of z)
           constexpr int NOCT = BM * (CC / 8);
@@ -933,6 +935,24 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
+  if constexpr (TW && WN <= 4) {
+    if (pp_opt_win_producers >= 3 && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {     // (3: also the temporal form -- A/B)
+      dim3 pblock(NT + 256);
+      if (bna) {
+        if constexpr (CC == 48) {
+          if (d.residual || gg.cg > 160 || d.bnr_partials) { pp_set_error("pp_igemm: fused BatchNorm apply: no residual, no backward sums, <= 160 channels"); return PP_ERR_INVALID; }
+          hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, true, false, true>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+          PP_LAUNCH_CHECK();
+          return PP_OK;
+        }
+      } else {
+        if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, true>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+        else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, true>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+        PP_LAUNCH_CHECK();
+        return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
+      }
+    }
+  }
   if constexpr (!TW) {
     // (1: where it pays -- tiles up to 128 columns; 144-column tiles keep 72 accumulators + 36 weight-fragment registers
     // and lose more to the 168-register budget than the producers give back: layer-1 forward 765 -> 845 us; 2: always)
