@@ -47,6 +47,13 @@ int pp_dtype(void);
  *                      are ordered in either mode
  *   "win_stagger"  0/1 window kernels with three weight slots: waves 4-7 request their fragments ahead of the K-step's
  *                      barrier, so that the two halves' LDS reads and MFMAs alternate instead of coinciding
+ *   "win_producers" 0..3  window kernels with four extra producer waves that issue every LDS-DMA (the eight multiplying
+ *                      waves issue none): 1 = spatial form, tiles up to 128 columns (default); 2 = every spatial tile;
+ *                      3 = also the temporal form; 0 = the lockstep kernels
+ *   "tw_producers" 0/1 temporal sliding-window weight gradient with three producer waves (default 1)
+ *   "tw_narrow"    0/1 its 48-channel form (deep look-ahead) for convolutions with at most 48 input channels (default 1)
+ *   "ln_bwd_alone" -1/0/1  pp_layernorm_bwd reserves LDS it never touches so that no LDS-using kernel shares its CUs
+ *                      (-1 = in deterministic mode, the default; why: DESIGN.md section 7)
  *   "win_out_nt"   0/1 non-temporal stores of the window kernels' output tiles (default 1)
  *   "bn_nt" b, "bn_grid" n   BatchNorm streaming passes: non-temporal loads (bit 0) / stores (bit 1), workgroups per launch
  *   "persist_cus"  n   workgroups of the persistent ring / window kernels (8..256, default 256 = one per CU) */
