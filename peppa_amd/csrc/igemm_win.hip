@@ -67,7 +67,7 @@ __device__ __forceinline__ void lds_dma16(const buffer_rsrc rs, unsigned char* d
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, off, 0, 0, 0);
 }
 
-__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uniform (0..8 here)
+__device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uniform (a producer wave keeps up to 35 pieces in flight)
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -78,6 +78,61 @@ __device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uni
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+    case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
+    case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+    case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
+    case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+    case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
+    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    case 49: asm volatile("s_waitcnt vmcnt(49)" ::: "memory"); break;
+    case 50: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
+    case 51: asm volatile("s_waitcnt vmcnt(51)" ::: "memory"); break;
+    case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+    case 53: asm volatile("s_waitcnt vmcnt(53)" ::: "memory"); break;
+    case 54: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
+    case 55: asm volatile("s_waitcnt vmcnt(55)" ::: "memory"); break;
+    case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    case 57: asm volatile("s_waitcnt vmcnt(57)" ::: "memory"); break;
+    case 58: asm volatile("s_waitcnt vmcnt(58)" ::: "memory"); break;
+    case 59: asm volatile("s_waitcnt vmcnt(59)" ::: "memory"); break;
+    case 60: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+    case 61: asm volatile("s_waitcnt vmcnt(61)" ::: "memory"); break;
+    case 62: asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); break;
+    case 63: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -154,11 +209,17 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   // and wait for them step by step; waves 4..7 issue only window pieces -- the WHOLE next window at the start of a
   // phase -- and wait for them once per phase, so a full window (40-70 KB per CU) is in flight under the phase's
   // matrix work instead of the one or two pieces a per-step wait allows.  All eight waves multiply.
-  constexpr int NPW = 2;                                      // producer waves per role (PROD)
-  constexpr int NWW = PROD ? NPW : NW / 2;                    // waves per role
+#ifndef PP_WIN_PROD_B
+#define PP_WIN_PROD_B 2
+#endif
+  // producer waves (PROD): two for the weight slices, two for the windows (tools/probe/win_prod_sweep.sh: three + one is
+  // no better for the 128- / 144-column tiles and loses the 512-row tile's gain -- its windows are 70 pieces a phase)
+  constexpr int NPB = TW ? 2 : PP_WIN_PROD_B, NPX = 4 - NPB;
+  constexpr int NWB = PROD ? NPB : NW / 2;                    // waves in the weight role
+  constexpr int NWX = PROD ? NPX : NW / 2;                    // waves in the window role
   static_assert(!PROD || (!BNR && !STG), "producer waves: plain epilogue");
-  constexpr int NWP = (WPIECES + NWW - 1) / NWW;              // window pieces per window wave and phase
-  constexpr int NBI = (BN + 8 * NWW - 1) / (8 * NWW);         // weight pieces per weight wave and K-step (last one maybe absent)
+  constexpr int NWP = (WPIECES + NWX - 1) / NWX;              // window pieces per window wave and phase
+  constexpr int NBI = (BN + 8 * NWB - 1) / (8 * NWB);         // weight pieces per weight wave and K-step (last one maybe absent)
   constexpr int NTAP = TW ? 3 : 9;
   constexpr int KC = NTAP * CC;                               // flat K of one channel chunk: (tap, channel)
   constexpr int NKC = (KC + BK - 1) / BK;                     // K-steps per chunk
@@ -182,10 +243,10 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // roles (wave-uniform)
   const bool is_comp = !PROD || wave < NW;
-  const bool win_wave = PROD ? wave >= NW + NPW : wave >= NWW;
-  const bool wgt_wave = PROD ? (wave >= NW && wave < NW + NPW) : wave < NWW;
-  const int rwave = PROD ? (win_wave ? wave - NW - NPW : (wgt_wave ? wave - NW : 0))   // index inside the role
-                         : (win_wave ? wave - NWW : wave);
+  const bool win_wave = PROD ? wave >= NW + NPB : wave >= NWB;
+  const bool wgt_wave = PROD ? (wave >= NW && wave < NW + NPB) : wave < NWB;
+  const int rwave = PROD ? (win_wave ? wave - NW - NPB : (wgt_wave ? wave - NW : 0))   // index inside the role
+                         : (win_wave ? wave - NWB : wave);
   const int fr = lane & 15, fq = lane >> 4;
   const int G = gridDim.x, bid = blockIdx.x;
   auto tile_index = [&](int it) __attribute__((always_inline)) -> int {   // persistent walk, XCD-contiguous (igemm.hip)
@@ -226,7 +287,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   unsigned w_voff[NVO];
 #pragma unroll
   for (int k = 0; k < NVO; ++k) {
-    const int q = rwave + NWW * k;
+    const int q = rwave + NWX * k;
     int row, cb;
     if (CC == 64) {
       row = q * 8 + (lane >> 3);
@@ -240,10 +301,10 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     const int rel = TW ? (lr >> g.pshift) * g.HW + (lr & (g.PB - 1)) : lr;
     w_voff[k] = (unsigned)(rel * g.cstride * 2 + cb);
   }
-  const unsigned w_step = WLIN ? (unsigned)(8 * NWW * g.cstride * 2) : 0u;   // bytes between a wave's consecutive pieces
+  const unsigned w_step = WLIN ? (unsigned)(8 * NWX * g.cstride * 2) : 0u;   // bytes between a wave's consecutive pieces
   // temporal form with a halo (kept only as staging room for wide outputs): its pieces are never read, so never fetched
   auto piece_live = [&](const int k) __attribute__((always_inline)) -> bool {
-    const int q = rwave + NWW * k;
+    const int q = rwave + NWX * k;
     if (TW && HALO_ > 0) return q * 1024 >= HALO_ * XS && (q + 1) * 1024 <= (HALO_ + BM) * XS;
     return q < WPIECES;
   };
@@ -261,7 +322,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     return (unsigned)(row0 * g.cstride + chunk_ * CC) * 2u;
   };
   auto dma_window_piece = [&](const int k, unsigned char* wbuf, const unsigned sbase) __attribute__((always_inline)) {
-    const int q = rwave + NWW * k;
+    const int q = rwave + NWX * k;
     if ((ABL & 2) && !abl_first) return;
     if (piece_live(k)) lds_dma16(rsA, wbuf + q * 1024, WLIN ? sbase + (unsigned)k * w_step + w_voff[0] : sbase + w_voff[k]);
   };
@@ -276,7 +337,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   constexpr unsigned ABSENT = 0x80000000u, ABSENT_K = 0x40000000u;   // (their sum does not wrap; Bt is < 2^30 bytes)
   const int brow0 = 8 * rwave + (lane >> 3);
   const int kqB = (lane & 7) ^ swz(brow0);
-  const bool b_last = 8 * rwave + 8 * NWW * (NBI - 1) < BN;   // does this wave own a piece in the last weight pass
+  const bool b_last = 8 * rwave + 8 * NWB * (NBI - 1) < BN;   // does this wave own a piece in the last weight pass
   const int nB = b_last ? NBI : NBI - 1;
   unsigned bvoff[NBI];
   // (64-channel chunks: K-step j is tap j, channels kqB * 8 ..: the lane's part moves into the row offset)
@@ -294,7 +355,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     unsigned char* dst = slot + (8 * rwave) * 128;
 #pragma unroll
     for (int i = 0; i < NBI; ++i)
-      if (i < NBI - 1 || b_last) lds_dma16(rsB, dst + 8 * NWW * i * 128, bvoff[i] + koff);
+      if (i < NBI - 1 || b_last) lds_dma16(rsB, dst + 8 * NWB * i * 128, bvoff[i] + koff);
   };
 
   // ---- per-tile state -------------------------------------------------------------------------------------------
@@ -305,7 +366,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     nb = tile - mb * nblk_n;
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
-      const int brow = brow0 + 8 * NWW * i;
+      const int brow = brow0 + 8 * NWB * i;
       const int n = nb * BN + brow;
       bvoff[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : ABSENT;
     }
