@@ -50,6 +50,7 @@ int pp_dtype(void);
  *   "win_producers" 0..3  window kernels with four extra producer waves that issue every LDS-DMA (the eight multiplying
  *                      waves issue none): 1 = spatial form, tiles up to 128 columns (default); 2 = every spatial tile;
  *                      3 = also the temporal form; 0 = the lockstep kernels
+ *   "ring_producers" 0/1 LDS-DMA ring GEMM / gather kernels with four producer waves, tiles up to 128 columns (default 1)
  *   "tw_producers" 0/1 temporal sliding-window weight gradient with three producer waves (default 1)
  *   "tw_narrow"    0/1 its 48-channel form (deep look-ahead) for convolutions with at most 48 input channels (default 1)
  *   "ln_bwd_alone" -1/0/1  pp_layernorm_bwd reserves LDS it never touches so that no LDS-using kernel shares its CUs

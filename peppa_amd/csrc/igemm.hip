@@ -14,6 +14,7 @@
 // LDS so every global store is a full 16-byte row segment.
 #include "common.h"
 #include <string.h>
+#include <type_traits>
 
 int pp_opt_xcd_remap_igemm = 1;
 int pp_opt_persistent = 1;
@@ -21,6 +22,7 @@ int pp_opt_win_tall = 1;       // window kernel: 512-row tiles (four row tiles p
 int pp_opt_deterministic = 0;   // ordered reductions instead of fp32 atomics wherever a sum crosses workgroups (slower; see the header)
 int pp_opt_tw_producers = 1;   // temporal sliding-window weight gradient: three extra waves issue the LDS-DMAs, the nine multiplying waves none
 int pp_opt_tw_narrow = 1;      // temporal sliding-window weight gradient: 48-channel blocks with a deep look-ahead for cg <= 48
+int pp_opt_ring_producers = 1;  // LDS-DMA ring GEMM: four extra waves issue the DMAs (tiles up to 128 columns)
 int pp_opt_ln_bwd_alone = -1;   // LayerNorm backward keeps LDS-using kernels off its CUs (-1: in deterministic mode, 0 / 1: never / always)
 int pp_opt_win_producers = 1;  // window kernel, spatial form: four extra waves issue the LDS-DMAs (1: tiles up to 128 columns, 2: all, 0: never)
 int pp_opt_win_stagger = 0;    // window kernel, spatial form: waves 4-7 request their fragments ahead of the K-step's barrier
@@ -52,6 +54,7 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "deterministic")) { pp_opt_deterministic = value ? 1 : 0; return PP_OK; }
   if (!strcmp(name, "tw_producers")) { pp_opt_tw_producers = value; return PP_OK; }
   if (!strcmp(name, "tw_narrow")) { pp_opt_tw_narrow = value; return PP_OK; }
+  if (!strcmp(name, "ring_producers")) { pp_opt_ring_producers = value; return PP_OK; }
   if (!strcmp(name, "ln_bwd_alone")) { pp_opt_ln_bwd_alone = value; return PP_OK; }
   if (!strcmp(name, "win_producers")) { pp_opt_win_producers = value; return PP_OK; }
   if (!strcmp(name, "win_stagger")) { pp_opt_win_stagger = value; return PP_OK; }
@@ -114,14 +117,19 @@ __device__ __forceinline__ void wait_vmcnt() {
 // RING = true : 256-row tiles (8 waves), one workgroup per CU; operands go global -> LDS by LDS-DMA
 //               (buffer_load ... lds) into a three-slot ring with two K-steps in flight across raw barriers and
 //               counted vmcnt waits.  The swizzled LDS image is the same: the XOR moves to the source address.
-template <int WN, int MODE, bool FULL, int NW, bool RING>
-__global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm_kernel(const pp_igemm_desc p, const int nblk_n,
+// PROD (ring only): four producer waves (threads 512 ..767) issue every LDS-DMA of a K-step, the eight multiplying waves
+// none (wgrad_tw.hip / igemm_win.hip measured why).  Twelve waves = 168 registers each; the tile loop is instantiated per
+// role so that the producers' row tables and the multipliers' accumulators are never live together.
+template <int WN, int MODE, bool FULL, int NW, bool RING, bool PROD = false>
+__global__ __launch_bounds__(64 * NW + (PROD ? 256 : 0), (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm_kernel(const pp_igemm_desc p, const int nblk_n,
                                                                        const RowDiv rd, const int xcd_remap, const int ntiles,
                                                                        const int out_nt) {
   static_assert(!RING || (NW == 8 && WN <= 9), "ring variant: 8 waves, BN <= 144");
+  static_assert(!PROD || RING, "producer waves: ring variant");
   constexpr int BM = 32 * NW;      // rows per workgroup: one 32-row slab per wave
-  constexpr int NT = 64 * NW;      // threads
-  constexpr int RS = NT / 8;       // row stride between a thread's chunks (8 chunk columns per 128-byte row)
+  constexpr int NT = 64 * NW;      // multiplying threads
+  constexpr int NTI = PROD ? 256 : NT;   // threads that load (stage) the operands
+  constexpr int RS = NTI / 8;      // row stride between a thread's chunks (8 chunk columns per 128-byte row)
   constexpr int BN = 16 * WN;
   constexpr int A_BYTES = BM * 128;
   constexpr int B_BYTES = BN * 128;
@@ -133,8 +141,8 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
   constexpr int NSLOT = RING ? 3 : 2;
   constexpr int SMEM = NSLOT * LOOP_BYTES > EPI_BYTES ? NSLOT * LOOP_BYTES : EPI_BYTES;
   static_assert(!RING || EPI_BYTES <= LOOP_BYTES, "the epilogue staging must fit one ring slot");
-  constexpr int NAI = 4;                       // A chunks per thread and K-step
-  constexpr int NBI = (BN * 8 + NT - 1) / NT;  // B chunks per thread and K-step
+  constexpr int NAI = BM / RS;                 // A chunks per loading thread and K-step (4; producers: 8)
+  constexpr int NBI = (BN * 8 + NTI - 1) / NTI;  // B chunks per loading thread and K-step
   // one LDS object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM + (MODE != PP_DENSE ? 2048 : 0)];
   int* const lut = (int*)(smem + SMEM);            // packed (dt, dh, dw) per tap
@@ -143,6 +151,9 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const bool is_comp = !PROD || tid < NT;      // (wave-uniform)
+  const int itid = PROD ? (tid - NT) & (NTI - 1) : tid;   // index among the loading threads (multiplying waves: unused)
+  const int iwave = itid >> 6;
   // Persistent workgroups: block b walks tiles b, b + G, b + 2G, ... (G = gridDim.x), prefetching the first K-step of
   // its next tile under the epilogue of the current one, so the cold-start load latency and the prologue are paid
   // once per workgroup instead of once per tile.
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
   // ---- per-thread bookkeeping: 4 A rows (tid>>3 + RS i) and NBI B rows, one 16-byte chunk column kq ----
   // register staging: thread loads chunk kq and stores it at slot kq ^ swz(row); LDS-DMA lands lane-linear, so the
   // thread owning slot (tid & 7) fetches chunk (tid & 7) ^ swz(row) instead (swz(row) is the same for all its rows)
-  const int kq = RING ? ((tid & 7) ^ swz(tid >> 3)) : (tid & 7);
+  const int kq = RING ? ((itid & 7) ^ swz(itid >> 3)) : (itid & 7);
   RowInfo ri[NAI];
   unsigned bbase[NBI];
   int kcur = 0;                 // this thread's k within the current K-step
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
     mb = tile / nblk_n;
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
-      const int m = mb * BM + (tid >> 3) + RS * i;
+      const int m = mb * BM + (itid >> 3) + RS * i;
       const bool valid = m < p.M;
       const int mm = valid ? m : 0;
       ri[i].nbase = 0;
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
     }
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
-      const int brow = (tid >> 3) + RS * i;
+      const int brow = (itid >> 3) + RS * i;
       const int n = nb * BN + brow;
       bbase[i] = (brow < BN && n < p.b_rows) ? (unsigned)(n * p.ldb) * 2u : OOB;
     }
@@ -303,12 +314,12 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
   };
   // LDS-DMA: one wave-instruction lands 64 x 16 B = eight 128-byte rows, lane-linear from a wave-uniform base; lanes
   // whose offset is OOB write zeros.  Every wave issues NAI pieces of A and NBI or NBI - 1 pieces of B per K-step.
-  const bool b_last = 8 * wave + RS * (NBI - 1) < BN;   // wave-uniform: does this wave own a piece in the last B pass
+  const bool b_last = 8 * iwave + RS * (NBI - 1) < BN;   // wave-uniform: does this wave own a piece in the last B pass
   auto dma_stage = [&](unsigned char* buf) __attribute__((always_inline)) {
     if (RING) {
       unsigned offA[NAI], offB[NBI];
       stage_offsets(offA, offB);
-      unsigned char* dst = buf + (8 * wave) * 128;
+      unsigned char* dst = buf + (8 * iwave) * 128;
 #pragma unroll
       for (int i = 0; i < NAI; ++i)
         lds_dma16(rsA, dst + RS * i * 128, offA[i]);
@@ -563,26 +574,35 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
   if (first < 0) return;
   setup_tile(first);
   if (RING) {
+    auto ring_loop = [&](auto comp_c) __attribute__((always_inline)) {
+    constexpr bool COMP = decltype(comp_c)::value;
+    constexpr bool DMA = !PROD || !COMP;
     // K-step s (counted over all tiles of this workgroup) lives in slot s % 3.  Per step: wait for this wave's
     // DMAs of the step (leaving the next one in flight), barrier (every wave's pieces have landed, and every wave
     // is done reading the slot about to be refilled), issue the step after next, compute.
     int s0 = 0;   // slot of this tile's first K-step
     auto slot = [&](int s) __attribute__((always_inline)) { return smem + (s >= 3 ? s - 3 : s) * LOOP_BYTES; };
-    dma_stage(slot(s0));
-    if (nk > 1) dma_stage(slot(s0 + 1));
+    if constexpr (DMA) {
+      dma_stage(slot(s0));
+      if (nk > 1) dma_stage(slot(s0 + 1));
+    }
     bool first_tile = true;
     while (true) {
+      if constexpr (COMP) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
       int sl = s0;
       for (int kt = 0; kt < nk; ++kt) {
         // (the first step of a later tile also has the previous epilogue's stores on the counter: drain them all)
-        wait_stage(kt + 1 < nk && (kt > 0 || first_tile));
+        if constexpr (DMA) wait_stage(kt + 1 < nk && (kt > 0 || first_tile));
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) dma_stage(slot(sl + 2));
-        compute(slot(sl));
+        if constexpr (DMA) {
+          if (kt + 2 < nk) dma_stage(slot(sl + 2));
+        }
+        if constexpr (COMP) compute(slot(sl));
         sl = sl == 2 ? 0 : sl + 1;
       }
       first_tile = false;
@@ -593,12 +613,25 @@ __global__ __launch_bounds__(64 * NW, (RING ? 1 : (WN <= 9 ? 2 : 1))) void igemm
       __builtin_amdgcn_s_barrier();   // every wave is done reading it
       if (next >= 0) {                // the next tile's first two K-steps fly under the epilogue
         setup_tile(next);
-        dma_stage(slot(sl));
-        if (nk > 1) dma_stage(slot(sl + 1));
+        if constexpr (DMA) {
+          dma_stage(slot(sl));
+          if (nk > 1) dma_stage(slot(sl + 1));
+        }
       }
-      epilogue(mb_done, nb_done, last);
+      if constexpr (COMP) {
+        epilogue(mb_done, nb_done, last);
+      } else if (!p.c_fp32 && p.colstats) {
+        __builtin_amdgcn_s_barrier();   // (the statistics' barrier inside the epilogue)
+      }
       if (next < 0) break;
       s0 = sl;
+    }
+    };
+    if constexpr (PROD) {
+      if (is_comp) ring_loop(std::true_type{});
+      else ring_loop(std::false_type{});
+    } else {
+      ring_loop(std::true_type{});
     }
     return;
   }
@@ -698,11 +731,23 @@ int launch_ring(const pp_igemm_desc& d, hipStream_t s) {
   const long long ntiles = nblk_m * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
-  dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(512);
+  dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(512), pblock(768);
   const RowDiv rd = make_rowdiv(d);
   const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;
-#define PP_LAUNCH_RING(MODE_, FULL_) \
-  hipLaunchKernelGGL((igemm_kernel<WN, MODE_, FULL_, 8, true>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, (int)ntiles, out_nt_for(d))
+  // producer form (pp_opt_ring_producers): tiles up to 128 columns -- the 144-column tile's multipliers do not fit 168 registers
+  const bool prod = pp_opt_ring_producers && WN <= 8;
+#define PP_LAUNCH_RING(MODE_, FULL_)                                                                                                   \
+  do {                                                                                                                                 \
+    if constexpr (WN <= 8) {                                                                                                           \
+      if (prod) {                                                                                                                      \
+        hipLaunchKernelGGL((igemm_kernel<WN, MODE_, FULL_, 8, true, true>), grid, pblock, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, \
+                           (int)ntiles, out_nt_for(d));                                                                                \
+        break;                                                                                                                         \
+      }                                                                                                                                \
+    }                                                                                                                                  \
+    hipLaunchKernelGGL((igemm_kernel<WN, MODE_, FULL_, 8, true>), grid, block, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm,            \
+                       (int)ntiles, out_nt_for(d));                                                                                    \
+  } while (0)
   switch (d.g.mode) {   // (fused epilogues: dense, and conv-forward at 128 columns -- the other conv forms would spill)
     case PP_DENSE:
       if (full) PP_LAUNCH_RING(PP_DENSE, true);
