@@ -735,10 +735,10 @@ int launch_ring(const pp_igemm_desc& d, hipStream_t s) {
   const RowDiv rd = make_rowdiv(d);
   const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;
   // producer form (pp_opt_ring_producers): tiles up to 128 columns -- the 144-column tile's multipliers do not fit 168 registers
-  const bool prod = pp_opt_ring_producers && WN <= 8;
+  const bool prod = pp_opt_ring_producers && WN <= 9;
 #define PP_LAUNCH_RING(MODE_, FULL_)                                                                                                   \
   do {                                                                                                                                 \
-    if constexpr (WN <= 8) {                                                                                                           \
+    if constexpr (WN <= 9) {                                                                                                           \
       if (prod) {                                                                                                                      \
         hipLaunchKernelGGL((igemm_kernel<WN, MODE_, FULL_, 8, true, true>), grid, pblock, 0, s, d, nblk_n, rd, pp_opt_xcd_remap_igemm, \
                            (int)ntiles, out_nt_for(d));                                                                                \
