@@ -544,6 +544,28 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     // one by one where they are used, every chunk exposed a full HBM round trip inside an epilogue nothing overlaps
     // (measured: the step 2.8 ms slower with the sums fused than with the separate pp_bn_bwd_reduce pass)
     uint4 ypre[BNR ? MT * NIT : 1];
+    // likewise the residual rows (RES): one 16-byte load per staged chunk, all in flight before the first row tile is staged
+    // (read where they are added, each exposed an HBM round trip: +120-140 us on the layer-1 data gradient)
+    // (512-row tiles, MT = 4: the four row tiles' chunks beside 64 accumulators spill under the producer form's 168
+    // registers and cost more than they save -- there only the next row tile's chunks are in flight)
+    constexpr int RPF = MT <= 2 ? MT : 1;             // row tiles of residual chunks requested ahead
+    uint4 rpre[RES ? MT * NIT : 1];
+    auto fetch_res = [&](const int mt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int cid = lane + 64 * it;
+        const int row = BNR ? b_rsub + RPI * it : cid / CPR;
+        const int ch = BNR ? b_ch : cid % CPR;
+        const bool live = BNR ? (b_rsub < RPI && row < 16) : cid < 32 * WN;
+        const int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
+        const int col = nb_e * BN + ch * 8;
+        rpre[mt * NIT + it] = (live && m < g.M && col < ncols_store) ? *(const uint4*)(p.residual + (long long)m * p.ldr + col) : make_uint4(0, 0, 0, 0);
+      }
+    };
+    if (RES) {
+#pragma unroll
+      for (int mt = 0; mt < RPF; ++mt) fetch_res(mt);
+    }
     if (BNR) {
       const int c0 = nb_e * BN + b_ch * 8;
       const bool cok = b_rsub < RPI && c0 < ncols_store;
@@ -567,6 +589,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      if (RES && mt + RPF < MT) fetch_res(mt + RPF);
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -600,7 +623,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
           const u32x4 vv = vvs[it];
           uint4 v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
           if (RES) {
-            const uint4 rv = *(const uint4*)(p.residual + (long long)m * p.ldr + col);
+            const uint4 rv = rpre[mt * NIT + it];
             float x[8], y[8];
             unpack8(v, x);
             unpack8(rv, y);
