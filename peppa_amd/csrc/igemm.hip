@@ -451,7 +451,22 @@ __global__ __launch_bounds__(64 * NW + (PROD ? 256 : 0), (RING ? 1 : (WN <= 9 ? 
 #pragma unroll
         for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vvs[it]));
       }
-#pragma unroll(FULL ? 1 : NIT)   // (rolled for the fused epilogues: their unrolled form spills)
+      // producer form: the multiplying waves hold no loader state, so the fused epilogue can be unrolled, and the residual
+      // chunks of the row tile are all requested before the first is added (one by one, each exposed a memory round trip
+      // inside an epilogue that nothing overlaps: the transformer's data gradients with residual are a dozen K-steps long)
+      constexpr bool RPRE = FULL && PROD && MODE == PP_DENSE && WN <= 8;   // (the 144-column tile spills unrolled)
+      uint4 rres[RPRE ? NIT : 1];
+      if (RPRE && residual) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int cid = lane + 64 * it;
+          const int m = m_wave + mt * 16 + cid / (2 * WN);
+          const int col = nb_e * BN + (cid % (2 * WN)) * 8;
+          rres[it] = (cid < 32 * WN && m < p.M && col < ncols_store) ? *(const uint4*)(residual + c_off + (long long)m * p.ldr + col)
+                                                                        : make_uint4(0, 0, 0, 0);
+        }
+      }
+#pragma unroll((FULL && !RPRE) ? 1 : NIT)   // (rolled for the lockstep fused epilogues: their unrolled form spills)
       for (int it = 0; it < NIT; ++it) {
         const int cid = lane + 64 * it;
         const int row = cid / (2 * WN);
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(64 * NW + (PROD ? 256 : 0), (RING ? 1 : (WN <= 9 ? 
             v = pack8(x);
           }
           if (FULL && residual) {
-            const uint4 rv = *(const uint4*)(residual + c_off + orow * p.ldr + col);
+            const uint4 rv = RPRE ? rres[RPRE ? it : 0] : *(const uint4*)(residual + c_off + orow * p.ldr + col);
             float x[8], y[8];
             unpack8(v, x);
             unpack8(rv, y);

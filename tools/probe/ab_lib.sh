@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of two BUILDS of libpeppa_hip.so on one box: bench.py alternately with tools/probe/prevlib/libpeppa_hip.so (built from
-# an earlier commit's sources) and the current library.     bash tools/probe/ab_lib.sh [rounds]
+# an earlier commit's sources) and the current library.     [CMD="python tools/probe/x.py"] bash tools/probe/ab_lib.sh [rounds]
 set -e
 cd "$(dirname "$0")/../.."
 cp peppa_amd/libpeppa_hip.so /tmp/peppa_new.so
@@ -8,7 +8,8 @@ for r in $(seq 1 ${1:-3}); do
   for which in prev new; do
     if [ $which = prev ]; then cp tools/probe/prevlib/libpeppa_hip.so peppa_amd/libpeppa_hip.so; else cp /tmp/peppa_new.so peppa_amd/libpeppa_hip.so; fi
     echo -n "$which: "
-    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step', d['value'], d['unit'])"
+    if [ -n "$CMD" ]; then $CMD 2>/dev/null | grep -v amdgpu; else
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step', d['value'], d['unit'])"; fi
   done
 done
 cp /tmp/peppa_new.so peppa_amd/libpeppa_hip.so
