@@ -129,22 +129,12 @@ __device__ __forceinline__ void keep8(uint32_t seed, long long chunk, uint32_t t
 // sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane, added in the order
 // (r0 + r1) + (r2 + r3) like `v += shfl_xor(v, 16); v += shfl_xor(v, 32)`.  gfx950's v_permlane16_swap / 32_swap do it
 // on the VALU; __shfl_xor goes through ds_bpermute (an LDS round trip per step).
-// The swaps go through inline asm with wait states on BOTH sides: as builtins hipcc puts `s_nop 1` in front of them and
-// lets the consuming v_add follow immediately, and a LayerNorm-backward row then came out with one lane's share missing from
-// its sums about once in 10^4 rows of the audio tower -- only inside the training step (other kernels' waves on the same
-// SIMD), never alone: run-to-run differences in deterministic mode (tools/probe/det_trace.py found the call).
-__device__ __forceinline__ void permlane16_swap(unsigned& a, unsigned& b) {
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
-}
 __device__ __forceinline__ float sum_rows4(float v) {
-  unsigned a = __float_as_uint(v), b = a;
-  permlane16_swap(a, b);                                                  // {r0,r0,r2,r2}, {r1,r1,r3,r3}
-  a = b = __float_as_uint(__uint_as_float(a) + __uint_as_float(b));
-  permlane32_swap(a, b);                                                  // {lo,lo}, {hi,hi}
-  return __uint_as_float(a) + __uint_as_float(b);
+  unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // {r0,r0,r2,r2}, {r1,r1,r3,r3}
+  u = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lo,lo}, {hi,hi}
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 // full-wave reductions on the VALU: DPP inside a 16-lane row (quad swaps, half-row mirror, row mirror), then the two
 // permlane swaps across rows; every lane gets the result.  (__shfl_xor = ds_bpermute: six LDS round trips.)
@@ -164,11 +154,11 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_f<0x4E>(v));
   v = fmaxf(v, dpp_f<0x141>(v));
   v = fmaxf(v, dpp_f<0x140>(v));
-  unsigned a = __float_as_uint(v), b = a;
-  permlane16_swap(a, b);
-  a = b = __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b)));
-  permlane32_swap(a, b);
-  return fmaxf(__uint_as_float(a), __uint_as_float(b));
+  unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+  const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 // sum over a block of NW waves; `red` needs NW floats of LDS; result valid in all threads
 template <int NW>
