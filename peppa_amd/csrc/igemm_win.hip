@@ -1020,7 +1020,7 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
   if constexpr (TW && WN <= 4) {
-    if (pp_opt_win_producers >= 3 && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {     // (3: also the temporal form -- A/B)
+    if (pp_opt_win_producers >= 3 && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {     // (3: also the temporal form)
       dim3 pblock(NT + 256);
       if (bna) {
         if constexpr (CC == 48) {
@@ -1040,7 +1040,7 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   if constexpr (!TW) {
     // (1: where it pays -- tiles up to 128 columns; 144-column tiles keep 72 accumulators + 36 weight-fragment registers
     // and lose more to the 168-register budget than the producers give back: layer-1 forward 765 -> 845 us; 2: always)
-    if ((pp_opt_win_producers == 2 || (pp_opt_win_producers == 1 && WN <= 8)) && !bna && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {
+    if ((pp_opt_win_producers == 2 || (pp_opt_win_producers != 0 && WN <= 8)) && !bna && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {
       dim3 pblock(NT + 256);
       if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, true>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
       else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, true>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);

@@ -66,8 +66,11 @@ def set_switch(name, on):
         PA.GROUP_WGRAD = on
     elif name == "win_producers_tw":          # the temporal form of the window kernel with producer waves as well (level 3)
         from peppa_amd import hip as H
-        H.set_option("win_producers", 3 if on else 1)
-    elif name in ("tw_producers", "tw_narrow", "win_producers", "ring_producers"):
+        H.set_option("win_producers", 3 if on else 1)   # (3 is the default)
+    elif name == "win_producers":
+        from peppa_amd import hip as H
+        H.set_option(name, 3 if on else 0)
+    elif name in ("tw_producers", "tw_narrow", "ring_producers"):
         from peppa_amd import hip as H
         H.set_option(name, 1 if on else 0)
     elif name == "win_stagger":
@@ -80,7 +83,7 @@ def set_switch(name, on):
         raise SystemExit(f"unknown switch {name}")
 
 
-defaults = {"ring_producers": True, "win_producers_tw": False, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
+defaults = {"ring_producers": True, "win_producers_tw": True, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
 for _ in range(3):
     step(0)
 for name in sys.argv[1:]:
