@@ -53,8 +53,8 @@ int pp_dtype(void);
  *   "ring_producers" 0/1 LDS-DMA ring GEMM / gather kernels with four producer waves, tiles up to 128 columns (default 1)
  *   "tw_producers" 0/1 temporal sliding-window weight gradient with three producer waves (default 1)
  *   "tw_narrow"    0/1 its 48-channel form (deep look-ahead) for convolutions with at most 48 input channels (default 1)
- *   "ln_bwd_alone" -1/0/1  pp_layernorm_bwd reserves LDS it never touches so that no LDS-using kernel shares its CUs
- *                      (-1 = in deterministic mode, the default; why: DESIGN.md section 7)
+ *   "ln_bwd_alone" 0/1  pp_layernorm_bwd reserves LDS it never touches so that no LDS-using kernel shares its CUs
+ *                      (default 0; an A/B switch from the investigation in DESIGN.md section 7)
  *   "win_out_nt"   0/1 non-temporal stores of the window kernels' output tiles (default 1)
  *   "bn_nt" b, "bn_grid" n   BatchNorm streaming passes: non-temporal loads (bit 0) / stores (bit 1), workgroups per launch
  *   "persist_cus"  n   workgroups of the persistent ring / window kernels (8..256, default 256 = one per CU) */

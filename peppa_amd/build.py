@@ -11,7 +11,12 @@ OUT = os.path.join(HERE, "libpeppa_hip.so")
 # flavour -> (shared object, extra compile flags, object directory): the same sources, bf16 and IEEE-half operands
 FLAVOURS = {"bf16": (OUT, [], "build"), "fp16": (os.path.join(HERE, "libpeppa_hip_f16.so"), ["-DPP_F16"], "build_f16")}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# -fno-slp-vectorize: no packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, which the SLP vectoriser
+# forms from pairs of scalar float operations).  With them, pp_layernorm_bwd returned one row of dx computed from slightly
+# wrong sums in about one launch of ten whenever waves of the register-staged GEMM / weight-gradient kernels shared its CUs;
+# without them, never (tools/probe/ln_variants.sh with EXTRA=-fno-slp-vectorize).  The MFMA kernels
+# have no use for the packed forms and the streaming kernels are HBM-bound: the step time is unchanged.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
 
 
 def _stale(target, deps):

@@ -11,7 +11,7 @@ constexpr int LN_BWD_ALONE_LDS = 92 * 1024;   // + the kernel's own 32 KB = 124 
 
 // experiment switches for tools/probe/ln_variants.sh (run-to-run differences of ln_bwd_kernel inside the step):
 // 1 wave sums through __shfl_xor, 2 no prefetch of the next row, 4 multiply by 1 / D instead of dividing, 8 full vmcnt wait
-// after the row's loads
+// after the row's loads, 16 no LDS (no dgamma / dbeta)
 #ifndef PP_LN_VARIANT
 #define PP_LN_VARIANT 0
 #endif
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const h16raw* __restrict__ 
       }
     }
   }
+#if !(PP_LN_VARIANT & 16)   // (16: no LDS at all -- dgamma / dbeta are then not produced)
   // combine the block's 4 waves in LDS, then one atomic per channel per block
   __shared__ float red[2][4][64 * 8 * LN_MAXC];
   const int w = threadIdx.x >> 6;
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const h16raw* __restrict__ 
       atomicAdd(dbeta + i, sb);
     }
   }
+#endif
 }
 
 __global__ __launch_bounds__(256) void ln_bwd_partials_kernel(const float* __restrict__ ws, int nblk, int D,
@@ -479,15 +481,15 @@ extern "C" int pp_layernorm_bwd(const void* dy, const void* x, const float* gamm
   const int rows_per_wave = (rows + waves - 1) / waves;
   waves = (rows + rows_per_wave - 1) / rows_per_wave;
   const int nblk = (waves + 3) / 4;
-  // Deterministic mode: the workgroup also reserves LN_BWD_ALONE_LDS bytes of LDS it never touches, which leaves less of
-  // a CU's 160 KB than any LDS-using kernel of this library needs: no such workgroup shares the CU.  Why: with waves of the
-  // register-staged GEMM / weight-gradient kernels (raw buffer loads) resident on the same CU, about one launch in ten
-  // returns one row of dx computed from sums in which one lane's 16 bytes of x were not the row's -- ~1e-3 of the row's
-  // gradient, so invisible in training, but two runs of a step then differ.  Never alone, never beside the LDS-DMA kernels
-  // (they fill the LDS themselves) or elementwise kernels; independent of the reduction, the prefetch and the division
-  // (tools/probe/ln_vs_kernels.py, ln_variants.sh, det_trace.py).  The cause below the ISA is open.
+  // pp_set_option("ln_bwd_alone", 1): the workgroup also reserves LN_BWD_ALONE_LDS bytes of LDS it never touches, which
+  // leaves less of a CU's 160 KB than any LDS-using kernel of this library needs, so none shares its CUs.  This was the first
+  // cure for a run-to-run difference of this kernel beside the register-staged GEMM / weight-gradient kernels (about one
+  // launch in ten returned one row of dx from slightly wrong sums; tools/probe/ln_vs_kernels.py, det_trace.py).  The cause
+  // turned out to be tied to the packed-FP32 instructions the SLP vectoriser formed here (v_pk_fma_f32 and friends): built
+  // with -fno-slp-vectorize (peppa_amd/build.py) the kernel is reproducible beside every neighbour WITHOUT the reservation,
+  // which therefore stays off; the switch remains for A/B runs.
   size_t dyn_lds = 0;
-  if (pp_opt_ln_bwd_alone < 0 ? pp_opt_deterministic : pp_opt_ln_bwd_alone) {
+  if (pp_opt_ln_bwd_alone > 0) {
     static bool attr_set = false;
     if (!attr_set) {
       const hipError_t e = hipFuncSetAttribute((const void*)ln_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LN_BWD_ALONE_LDS);

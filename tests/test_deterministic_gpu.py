@@ -128,10 +128,11 @@ def test_weight_gradient_slabs_match_the_atomic_path(deterministic):
 
 
 def test_layernorm_backward_is_reproducible_beside_the_register_staged_kernels(deterministic):
-    """pp_layernorm_bwd on fixed inputs while a second stream runs the generic weight-gradient kernel (the kernels that
-    stage their operands through registers share CUs with it: with such a neighbour about one launch in ten used to return
-    a row of dx computed from slightly different sums -- tools/probe/ln_vs_kernels.py).  In deterministic mode the launch
-    keeps LDS-using kernels off its CUs (pp_set_option("ln_bwd_alone")), and every launch returns the same bits."""
+    """pp_layernorm_bwd on fixed inputs while a second stream runs the generic weight-gradient kernel.  The kernels that
+    stage their operands through registers share CUs with it, and with such a neighbour about one launch in ten used to return
+    a row of dx computed from slightly different sums -- as long as the library was built with packed-FP32 instructions
+    (the SLP vectoriser's v_pk_fma_f32 ...); peppa_amd/build.py passes -fno-slp-vectorize since, and every launch returns
+    the same bits (tools/probe/ln_vs_kernels.py, ln_variants.sh)."""
     from peppa_amd import layers as L
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(3)

@@ -17,6 +17,8 @@ from peppa_amd.data import synthetic_batch
 import test_deterministic_gpu as T
 
 H.set_deterministic(True)
+if "LN_BWD_ALONE" in os.environ:
+    H.set_option("ln_bwd_alone", int(os.environ["LN_BWD_ALONE"]))
 net = T._net(T._cfg())
 state = copy.deepcopy(net.state_dict())
 batch = synthetic_batch(2, 16, 112, 36800).to("cuda")
