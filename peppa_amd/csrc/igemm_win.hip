@@ -58,6 +58,7 @@ constexpr int HALO = 64;                      // rows kept on either side of the
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) buffer_rsrc;
 
@@ -192,6 +193,17 @@ template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, 
 __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap, const int out_nt) {
   constexpr int BM = 16 * MT * NW;
+  // TRC: the MFMAs take (weights, activations) instead of (activations, weights), i.e. accumulate the TRANSPOSED tile: a lane
+  // then holds four consecutive output COLUMNS of one output row (row = lane & 15, columns 4 (lane >> 4) ..), which is 8
+  // contiguous bytes of C -- the epilogue stages a row tile in LDS with 18 eight-byte writes per lane instead of the 72
+  // two-byte writes the other layout (four consecutive rows of one column) needs, before the same coalesced 16-byte
+  // stores.  (Storing the 8 bytes straight from the accumulators was tried: 32-byte partial-line writes, step +0.5 ms.)
+  // Not with BNR (its epilogue keeps a fixed 8-column chunk per lane for the BatchNorm-backward sums; bnr_built() kernels
+  // keep the untransposed form).
+#ifndef PP_WIN_DIRECT_EPILOGUE
+#define PP_WIN_DIRECT_EPILOGUE 1
+#endif
+  constexpr bool TRC = PP_WIN_DIRECT_EPILOGUE && !BNR;
   // temporal tiles with narrow outputs: no halo rows at all and THREE window buffers -- the window of the phase after
   // next is in flight too, because a phase (3 short K-steps) is far shorter than an HBM round trip
   constexpr int HALO_ = (TW && WN <= 4) ? 0 : HALO;
@@ -517,7 +529,8 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
       for (int jn = 0; jn < WN; ++jn) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt][jn] = PP_MFMA16(af[ks][mt], bfm[REUSE_B ? 0 : ks][jn], acc[mt][jn], 0, 0, 0);
+          acc[mt][jn] = TRC ? PP_MFMA16(bfm[REUSE_B ? 0 : ks][jn], af[ks][mt], acc[mt][jn], 0, 0, 0)
+                            : PP_MFMA16(af[ks][mt], bfm[REUSE_B ? 0 : ks][jn], acc[mt][jn], 0, 0, 0);
         if (REUSE_B && ks == 0) {          // (pinned: left alone, hipcc sinks these reads to just before their MFMAs)
           bfm[0][jn] = load_b(1, jn);
           __builtin_amdgcn_sched_barrier(0);
@@ -591,9 +604,15 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     for (int mt = 0; mt < MT; ++mt) {
       if (RES && mt + RPF < MT) fetch_res(mt + RPF);
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+      for (int j = 0; j < WN; ++j) {
+        if (TRC) {        // four consecutive columns of row fr: one 8-byte write (acc[mt][j][r] = C[row fr][j * 16 + 4 fq + r])
+          const u32x2 w = {pack2(acc[mt][j][0], acc[mt][j][1]), pack2(acc[mt][j][2], acc[mt][j][3])};
+          *(u32x2*)(stg + fr * STG_STRIDE + j * 32 + fq * 8) = w;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *(h16raw*)(stg_w + r * STG_STRIDE + j * 32) = f2h(acc[mt][j][r]);
+          for (int r = 0; r < 4; ++r) *(h16raw*)(stg_w + r * STG_STRIDE + j * 32) = f2h(acc[mt][j][r]);
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       // all of the pass's staged chunks are requested, then ONE wait (one wait per chunk exposed an LDS round trip each).
@@ -707,6 +726,23 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
       float* statbuf = (float*)sbuf;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
+        if (TRC) {
+          // a column's 32 rows of this wave: two row tiles in the lane, sixteen lanes of a DPP row (same fq) across
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a0 = acc[0][j][r], a1 = acc[MT == 2 ? 1 : 0][j][r];
+            float s1 = a0 + a1, s2 = a0 * a0 + a1 * a1;
+            s1 += dpp_f<0xB1>(s1);  s2 += dpp_f<0xB1>(s2);     // lane ^ 1
+            s1 += dpp_f<0x4E>(s1);  s2 += dpp_f<0x4E>(s2);     // lane ^ 2
+            s1 += dpp_f<0x141>(s1); s2 += dpp_f<0x141>(s2);    // the other quad of the half row
+            s1 += dpp_f<0x140>(s1); s2 += dpp_f<0x140>(s2);    // the other half of the 16-lane row
+            if (fr == 0) {
+              statbuf[(wave * BN + j * 16 + 4 * fq + r) * 2 + 0] = s1;
+              statbuf[(wave * BN + j * 16 + 4 * fq + r) * 2 + 1] = s2;
+            }
+          }
+          continue;
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int mt = 0; mt < (MT == 2 ? 2 : 0); ++mt)
@@ -1040,7 +1076,7 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   if constexpr (!TW) {
     // (1: where it pays -- tiles up to 128 columns; 144-column tiles keep 72 accumulators + 36 weight-fragment registers
     // and lose more to the 168-register budget than the producers give back: layer-1 forward 765 -> 845 us; 2: always)
-    if ((pp_opt_win_producers == 2 || (pp_opt_win_producers != 0 && WN <= 8)) && !bna && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {
+    if ((pp_opt_win_producers == 2 || pp_opt_win_producers == 4 || (pp_opt_win_producers != 0 && WN <= 8)) && !bna && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {
       dim3 pblock(NT + 256);
       if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, true>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
       else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, true>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);

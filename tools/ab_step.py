@@ -66,10 +66,13 @@ def set_switch(name, on):
         PA.GROUP_WGRAD = on
     elif name == "win_producers_tw":          # the temporal form of the window kernel with producer waves as well (level 3)
         from peppa_amd import hip as H
-        H.set_option("win_producers", 3 if on else 1)   # (3 is the default)
+        H.set_option("win_producers", 4 if on else 2)   # (4 is the default)
+    elif name == "win_producers_all":         # also the 144-column spatial tiles (level 4) against level 3
+        from peppa_amd import hip as H
+        H.set_option("win_producers", 4 if on else 3)
     elif name == "win_producers":
         from peppa_amd import hip as H
-        H.set_option(name, 3 if on else 0)
+        H.set_option(name, 4 if on else 0)
     elif name in ("tw_producers", "tw_narrow", "ring_producers"):
         from peppa_amd import hip as H
         H.set_option(name, 1 if on else 0)
@@ -83,7 +86,7 @@ def set_switch(name, on):
         raise SystemExit(f"unknown switch {name}")
 
 
-defaults = {"ring_producers": True, "win_producers_tw": True, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
+defaults = {"win_producers_all": True, "ring_producers": True, "win_producers_tw": True, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
 for _ in range(3):
     step(0)
 for name in sys.argv[1:]:
