@@ -200,10 +200,10 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   // stores.  (Storing the 8 bytes straight from the accumulators was tried: 32-byte partial-line writes, step +0.5 ms.)
   // Not with BNR (its epilogue keeps a fixed 8-column chunk per lane for the BatchNorm-backward sums; bnr_built() kernels
   // keep the untransposed form).
-#ifndef PP_WIN_DIRECT_EPILOGUE
-#define PP_WIN_DIRECT_EPILOGUE 1
+#ifndef PP_WIN_TRANSPOSED_ACC
+#define PP_WIN_TRANSPOSED_ACC 1
 #endif
-  constexpr bool TRC = PP_WIN_DIRECT_EPILOGUE && !BNR;
+  constexpr bool TRC = PP_WIN_TRANSPOSED_ACC && !BNR;
   // temporal tiles with narrow outputs: no halo rows at all and THREE window buffers -- the window of the phase after
   // next is in flight too, because a phase (3 short K-steps) is far shorter than an HBM round trip
   constexpr int HALO_ = (TW && WN <= 4) ? 0 : HALO;
