@@ -49,7 +49,7 @@ int pp_dtype(void);
  *                      barrier, so that the two halves' LDS reads and MFMAs alternate instead of coinciding
  *   "win_producers" 0..3  window kernels with four extra producer waves that issue every LDS-DMA (the eight multiplying
  *                      waves issue none): 1 = spatial form, tiles up to 128 columns; 2 = every spatial tile; 3 = 1 + the
- *                      temporal form with tiles up to 64 columns; 4 = 2 + that temporal form (default); 0 = the lockstep
+ *                      temporal form; 4 = 2 + the temporal form (default); 0 = the lockstep
  *                      kernels
  *   "ring_producers" 0/1 LDS-DMA ring GEMM / gather kernels with four producer waves, tiles up to 128 columns (default 1)
  *   "tw_producers" 0/1 temporal sliding-window weight gradient with three producer waves (default 1)

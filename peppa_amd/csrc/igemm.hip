@@ -24,7 +24,7 @@ int pp_opt_tw_producers = 1;   // temporal sliding-window weight gradient: three
 int pp_opt_tw_narrow = 1;      // temporal sliding-window weight gradient: 48-channel blocks with a deep look-ahead for cg <= 48
 int pp_opt_ring_producers = 1;  // LDS-DMA ring GEMM: four extra waves issue the DMAs (tiles up to 128 columns)
 int pp_opt_ln_bwd_alone = 0;    // LayerNorm backward keeps LDS-using kernels off its CUs (A/B switch; see pp_layernorm_bwd)
-int pp_opt_win_producers = 4;  // window kernel: four extra waves issue the LDS-DMAs (0: never; 1: spatial form, tiles up to 128 columns; 2: every spatial tile; 3 = 1 + the temporal form with tiles up to 64 columns; 4 = 2 + that temporal form, the default)
+int pp_opt_win_producers = 4;  // window kernel: four extra waves issue the LDS-DMAs (0: never; 1: spatial form, tiles up to 128 columns; 2: every spatial tile; 3 = 1 + the temporal form; 4 = 2 + the temporal form, the default)
 int pp_opt_win_stagger = 0;    // window kernel, spatial form: waves 4-7 request their fragments ahead of the K-step's barrier
 int pp_opt_win_temporal = 1;   // window kernel also for (3,1,1) stride-1 convs (frames-by-positions tiles)
 int pp_opt_win_igemm = 1024;   // window kernel for (1,3,3) stride-1 convs (forward / data gradient) once M >= this (0 = never)

@@ -1055,7 +1055,7 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
-  if constexpr (TW && WN <= 4) {
+  if constexpr (TW) {
     if (pp_opt_win_producers >= 3 && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {     // (3: also the temporal form)
       dim3 pblock(NT + 256);
       if (bna) {
