@@ -3,6 +3,9 @@
 # an earlier commit's sources) and the current library.     [CMD="python tools/probe/x.py"] bash tools/probe/ab_lib.sh [rounds]
 set -e
 cd "$(dirname "$0")/../.."
+# build the other library first, e.g.:  git stash; python -c "import __graft_entry__ as g; g.build()"; mkdir -p tools/probe/prevlib;
+#   cp peppa_amd/libpeppa_hip.so tools/probe/prevlib/; git stash pop; python -c "import __graft_entry__ as g; g.build()"
+[ -f tools/probe/prevlib/libpeppa_hip.so ] || { echo "tools/probe/prevlib/libpeppa_hip.so is missing (see the comment above)"; exit 1; }
 cp peppa_amd/libpeppa_hip.so /tmp/peppa_new.so
 for r in $(seq 1 ${1:-3}); do
   for which in prev new; do
