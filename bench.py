@@ -32,7 +32,8 @@ def train_flops_per_pair(frames, size, samples, frozen_audio=False):
     """Algorithmic FLOPs of one training step per clip pair: r2plus1d_18 scales with
     frames x pixels, wav2vec2 with its frame count (229 frames: 65.76 GF; the quadratic attention term is < 2 %)."""
     T = (samples - 400) // 320 + 1
-    video = 81.04e9 * (frames / 16.0) * (size / 112.0) ** 2
+    H, W = (size, size) if isinstance(size, int) else size
+    video = 81.04e9 * (frames / 16.0) * (H * W / 112.0 ** 2)
     audio = {114: 32.30e9, 229: 65.76e9, 49: 13.82e9}.get(T, 32.30e9 * T / 114.0)
     if frozen_audio:      # hparams_freeze_wav2vec: forward + data gradient through the frozen layers (SURVEY 8d: ~298 GF at C2)
         return 3 * video + audio + 22.56e9 * (audio / 32.30e9)
@@ -50,15 +51,21 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=16)
-    ap.add_argument("--size", type=int, default=112)
+    ap.add_argument("--size", default="112", help="frame size H or HxW (the reference's own clips: 100x180, 23 frames, "
+                    "101429 audio samples = 2.3 s at 44.1 kHz fed unresampled: hparams_base.yaml:9,14-16, SURVEY 0.8)")
     ap.add_argument("--samples", type=int, default=36800)
+    ap.add_argument("--audio-rate", type=int, default=16000, help="only labels the workload (the model sees samples)")
     ap.add_argument("--config", default=os.path.join(ROOT, "hparams_base.yaml"))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit operand type: bf16 (BASELINE configs[1]) or fp16 + dynamic loss scaling (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="no HIP events inside the timed region (roofline: null)")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    return ap.parse_args()
+    args = ap.parse_args()
+    hw = [int(v) for v in str(args.size).lower().split("x")]
+    args.size = hw[0] if len(hw) == 1 or hw[0] == hw[1] else (hw[0], hw[1])
+    args.size_name = f"{hw[0]}x{hw[-1]}"
+    return args
 
 
 def cpu_baseline(cfg, args):
@@ -92,7 +99,7 @@ def cpu_baseline(cfg, args):
             break
     return {"value": args.cpu_batch * nsteps / dt, "unit": "clip-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{nsteps} full training steps (fwd+loss+bwd+BertAdam) of the fp32 CPU oracle at batch {args.cpu_batch}, "
-                      f"{args.frames}x{args.size}x{args.size} video + {args.samples} audio samples, {dt:.1f} s"}
+                      f"{args.frames}x{args.size_name} video + {args.samples} audio samples, {dt:.1f} s"}
 
 
 def main():
@@ -264,8 +271,8 @@ def main():
         "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{cfg_name} training step, {args.frames}x{args.size}x{args.size} video + "
-                               f"{args.samples / 16000:.1f} s@16kHz audio, batch {args.batch}/GPU{which}",
+        "config": {"workload": f"{cfg_name} training step, {args.frames}x{args.size_name} video + "
+                               f"{args.samples / args.audio_rate:.1f} s@{args.audio_rate / 1000:g}kHz audio, batch {args.batch}/GPU{which}",
                    "global_batch": world * args.batch,
                    "parallelism": f"dp{world}" + ("+rccl" if use_dist and world == 1 else "")
                                   + (" (gloo, ranks share cuda:0: rehearsal of the launch path, not a scaling number)" if share_gpu and world > 1 else ""),

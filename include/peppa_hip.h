@@ -28,6 +28,10 @@ int pp_version(void);
  * (hparams_base.yaml:45, BASELINE configs[4]).  Wherever this header says "bf16" for an operand it means that type. */
 enum pp_dtype_t { PP_DTYPE_BF16 = 0, PP_DTYPE_F16 = 1 };
 int pp_dtype(void);
+/* non-zero when the library was compiled with one of the experiment macros of tools/probe/ (PP_WIN_ABLATE bit 0,
+ * PP_TW_ABLATE bit 1, PP_LN_VARIANT bit 2): ablation builds whose RESULTS ARE WRONG by design, or kernel variants under
+ * test.  The Python binding refuses such a library unless PEPPA_ALLOW_EXPERIMENTAL=1; the shipped build returns 0. */
+int pp_experimental_build(void);
 /* tuning switches (process-wide; also PEPPA_HIP_OPTIONS="name=value,..." through the Python loader):
  *   "xcd_remap_igemm", "xcd_remap_wgrad"  0/1   XCD-contiguous tile order
  *   "persistent_igemm"                    0/1   persistent workgroups with cross-tile prefetch (plain epilogues)

@@ -250,6 +250,7 @@ class PeppaPigOracle(nn.Module):
 def synthetic_batch(batch, frames, size, samples, seed=1234):
     """SURVEY 8d synthetic inputs: video U[0,1), audio 0.1*N(0,1), CPU generator."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    video = torch.rand(batch, 3, frames, size, size, generator=g)
+    H, W = (size, size) if isinstance(size, int) else size
+    video = torch.rand(batch, 3, frames, H, W, generator=g)
     audio = 0.1 * torch.randn(batch, 1, samples, generator=g)
     return video, audio

@@ -9,7 +9,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpeppa_hip.so")
 # one shared object per 16-bit operand type (same sources, include/peppa_hip.h `pp_dtype`)
-LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libpeppa_hip_f16.so")}
+# PEPPA_HIP_LIB / PEPPA_HIP_LIB_F16: another build of the same library (tools/probe/*.sh link their variants to /tmp and
+# point the binding there; the shipped files are never overwritten by an experiment)
+LIB_PATHS = {"bf16": os.environ.get("PEPPA_HIP_LIB", LIB_PATH),
+             "fp16": os.environ.get("PEPPA_HIP_LIB_F16", os.path.join(_HERE, "libpeppa_hip_f16.so"))}
 PRECISION = "bf16"    # which of the two `call` dispatches to (peppa_amd.hip.set_precision)
 
 
@@ -62,6 +65,7 @@ P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 SIGNATURES = {
     "pp_version": [],
     "pp_dtype": [],
+    "pp_experimental_build": [],
     "pp_grad_unscale_check": [C.POINTER(TensorList), P, P, I, I, P, P, P],
     "pp_amp_update_scale": [P, P, P, F, F, I, P],
     "pp_last_error": [],
@@ -138,9 +142,10 @@ SIGNATURES = {
     "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P, P, P],
 }
 _RESTYPE = {"pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z, "pp_wgrad_ws_floats": L}
-_NO_STATUS = set(_RESTYPE) | {"pp_version", "pp_dtype"}
+_NO_STATUS = set(_RESTYPE) | {"pp_version", "pp_dtype", "pp_experimental_build"}
 
 _libs = {}
+STICKY_OPTIONS = {}   # options set through peppa_amd.hip (e.g. deterministic): applied to a build that is loaded later
 
 
 def lib(precision=None):
@@ -160,12 +165,20 @@ def lib(precision=None):
             fn.restype = _RESTYPE.get(name, C.c_int)
         if h.pp_dtype() != {"bf16": 0, "fp16": 1}[precision]:
             raise PeppaHipError(f"{path} was not built for {precision} operands (pp_dtype = {h.pp_dtype()})")
+        exp = h.pp_experimental_build()
+        if exp and os.environ.get("PEPPA_ALLOW_EXPERIMENTAL") != "1":
+            raise PeppaHipError(f"{path} was built with experiment macros (pp_experimental_build = {exp}: PP_WIN_ABLATE 1, "
+                                "PP_TW_ABLATE 2, PP_LN_VARIANT 4): ablation / variant builds of tools/probe/, whose results "
+                                "may be wrong by design.  Rebuild with peppa_amd.build, or set PEPPA_ALLOW_EXPERIMENTAL=1")
         _libs[precision] = h
         # tuning switches for A/B measurements: PEPPA_HIP_OPTIONS="ring_igemm=0,xcd_remap_wgrad=0"
         for item in filter(None, os.environ.get("PEPPA_HIP_OPTIONS", "").split(",")):
             key, _, val = item.partition("=")
             if h.pp_set_option(key.strip().encode(), int(val)) != 0:
                 raise PeppaHipError(f"PEPPA_HIP_OPTIONS: {h.pp_last_error().decode()}")
+        for key, val in STICKY_OPTIONS.items():
+            if h.pp_set_option(key.encode(), int(val)) != 0:
+                raise PeppaHipError(f"pp_set_option({key}): {h.pp_last_error().decode()}")
     return _libs[precision]
 
 

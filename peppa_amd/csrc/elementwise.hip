@@ -11,6 +11,10 @@ void pp_set_error(const char* fmt, ...) {
 }
 extern "C" const char* pp_last_error(void) { return g_err; }
 extern "C" int pp_version(void) { return 200; }
+extern const int pp_exp_win_ablate, pp_exp_tw_ablate, pp_exp_ln_variant;   // igemm_win.hip, wgrad_tw.hip, norm.hip
+extern "C" int pp_experimental_build(void) {
+  return (pp_exp_win_ablate != 0) | ((pp_exp_tw_ablate != 0) << 1) | ((pp_exp_ln_variant != 0) << 2);
+}
 #ifdef PP_F16
 extern "C" int pp_dtype(void) { return PP_DTYPE_F16; }
 #else

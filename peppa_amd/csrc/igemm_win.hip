@@ -41,6 +41,9 @@ extern int pp_opt_win_producers;
 namespace {
 
 constexpr int ABL = PP_WIN_ABLATE;
+}
+extern const int pp_exp_win_ablate = PP_WIN_ABLATE;   // reported by pp_experimental_build()
+namespace {
 #if PP_WIN_ABLATE & 64
 __device__ unsigned long long pp_win_stamp_buf[256 * 8 * 8];
 #define PP_STAMP(i)                                                      \

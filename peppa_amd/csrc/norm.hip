@@ -15,6 +15,9 @@ constexpr int LN_BWD_ALONE_LDS = 92 * 1024;   // + the kernel's own 32 KB = 124 
 #ifndef PP_LN_VARIANT
 #define PP_LN_VARIANT 0
 #endif
+}
+extern const int pp_exp_ln_variant = PP_LN_VARIANT;   // reported by pp_experimental_build()
+namespace {
 __device__ __forceinline__ float ln_wave_sum(float v) {
 #if PP_LN_VARIANT & 1
 #pragma unroll

@@ -30,6 +30,9 @@ void pp_wgrad_slab_sum(const float* ws, int nsplit, long long slab_floats, int N
 namespace {
 
 constexpr int ABL = PP_TW_ABLATE;
+}
+extern const int pp_exp_tw_ablate = PP_TW_ABLATE;   // reported by pp_experimental_build()
+namespace {
 constexpr int MS = 64;                 // rows (positions hw) per step
 constexpr int NWV = 9;                 // multiplying waves
 constexpr int NT = 64 * NWV;

@@ -125,7 +125,8 @@ def collate_device(clips, device="cuda", video_dtype=torch.float32, fps=10, audi
 def synthetic_batch(batch, frames, size, samples, seed=1234, device="cpu"):
     """SURVEY 8d synthetic clips: video U[0,1) (frame/255), audio 0.1*N(0,1), CPU generator."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    video = torch.rand(batch, 3, frames, size, size, generator=g)
+    H, W = (size, size) if isinstance(size, int) else size     # (H, W): the reference's own frames are 100 x 180 (SURVEY 0.8)
+    video = torch.rand(batch, 3, frames, H, W, generator=g)
     audio = 0.1 * torch.randn(batch, 1, samples, generator=g)
     # seconds, as in the reference's batches: 10 fps video snippets, 16 kHz synthetic audio (SURVEY 0.8 / 8d)
     return ClipBatch(video.to(device), audio.to(device), torch.full((batch,), frames / 10.0),

@@ -58,19 +58,25 @@ DETERMINISTIC = False
 
 
 def set_deterministic(on=True):
-    """pp_set_option("deterministic", ...) in BOTH builds of the library + the workspaces the wrappers below then pass:
-    every sum that crosses workgroups is taken in a fixed order instead of by fp32 atomics, so two runs of the same step
-    give bitwise-identical losses, gradients and updates (include/peppa_hip.h; cost: DESIGN.md section 7).  Returns the
-    previous setting.  `mi355x: {deterministic: true}` in the yaml / `run.py --deterministic` switch it on."""
+    """pp_set_option("deterministic", ...) in every build of the library that is loaded or present + the workspaces the
+    wrappers below then pass: every sum that crosses workgroups is taken in a fixed order instead of by fp32 atomics, so two
+    runs of the same step give bitwise-identical losses, gradients and updates (include/peppa_hip.h; cost: DESIGN.md
+    section 7).  Returns the previous setting.  `mi355x: {deterministic: true}` in the yaml / `run.py --deterministic`
+    switch it on.  The mode is PROCESS-GLOBAL (a C option of the library, like torch.use_deterministic_algorithms): a
+    model built with the yaml switch turns it on for every model of the process; callers that want it scoped restore
+    the returned value in a `finally`.  A build that is not there (a bf16-only install) is skipped and gets the option
+    when it is loaded later (`_lib.lib` applies `_lib.STICKY_OPTIONS`); the Python flag only changes after every C call
+    has succeeded, so a failure cannot leave the wrappers and the library disagreeing about the workspaces."""
     global DETERMINISTIC
-    prev, DETERMINISTIC = DETERMINISTIC, bool(on)
-    cur = _lib.PRECISION
+    import os
+    on = bool(on)
     for prec in ("bf16", "fp16"):
-        _lib.PRECISION = prec
-        try:
-            call("pp_set_option", b"deterministic", int(bool(on)))
-        finally:
-            _lib.PRECISION = cur
+        if prec in _lib._libs or os.path.exists(_lib.LIB_PATHS[prec]):
+            h = _lib.lib(prec)
+            if h.pp_set_option(b"deterministic", int(on)) != 0:
+                raise PeppaHipError(f"pp_set_option(deterministic) [{prec}]: {h.pp_last_error().decode()}")
+    _lib.STICKY_OPTIONS["deterministic"] = int(on)
+    prev, DETERMINISTIC = DETERMINISTIC, on
     return prev
 
 
@@ -562,6 +568,13 @@ def triplet_accuracy(a, p, n, discrete, out):
 
 # ---- optimizer -------------------------------------------------------------------------------------
 def bertadam_step(tl, chunk_tensor, chunk_off, n_chunks, chunk, norms, lr, b1, b2, eps, wd, max_norm, lr_t=None, skip=None):
+    # `norms` is scratch the C entry point cannot size-check: [n_tensors] squared norms, and in the deterministic mode
+    # sumsq_kernel also writes one partial per chunk behind them (csrc/optim.hip) -- a short buffer would be a silent
+    # out-of-bounds device write
+    need = tl.n_tensors + (n_chunks if DETERMINISTIC else 0)
+    if norms.numel() < need:
+        raise PeppaHipError(f"pp_bertadam_step: `norms` holds {norms.numel()} floats, needs {need} "
+                            f"(n_tensors{' + n_chunks in the deterministic mode' if DETERMINISTIC else ''})")
     call("pp_bertadam_step", C.byref(tl), _p(chunk_tensor, torch.int32), _p(chunk_off, torch.int64), n_chunks, chunk,
          _p(norms, f32), lr, b1, b2, eps, wd, max_norm, _p(lr_t, f32), _p(skip, f32), _s())
 

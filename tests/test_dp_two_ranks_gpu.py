@@ -104,41 +104,43 @@ def test_two_ranks_match_one_process_on_the_global_batch(tmp_path, layer_drop, a
     mp.spawn(_worker, args=(world, port, out, layer_drop, accumulate, det), nprocs=world, join=True)
     got = torch.load(out)
     prev = H.set_deterministic(det)
-    # one process, the global batch, plain BatchNorm over all 2B clips (= what SyncBN computes across the two ranks)
-    net = _net(_cfg(False), layer_drop)
-    losses = []
-    for k, gb in enumerate(_batches(world, accumulate)):
-        loss, obj = _objective(net, gb.to("cuda"), k, world)
-        (obj / accumulate).backward()
-        losses.append(loss)
-    torch.cuda.synchronize()
-    print("losses", losses, got["loss"], "early hand-offs", got["pushed"])
-    assert got["pushed"] > 150
-    for a, b in zip(losses, got["loss"]):
-        assert abs(a - b) <= (1e-6 if det else 2e-3), (losses, got["loss"])
-    ref = {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None}
-    assert set(ref) == set(got["grads"]), set(ref) ^ set(got["grads"])      # same tensors skipped by LayerDrop / unused
-    if layer_drop > 0:
-        assert len(ref) < sum(1 for _ in net.parameters()) - 2              # (some layer was dropped in both micro-batches or fc)
-    # per group: pooled relative error, ratio of the pooled norms, pooled cosine (tensors whose true gradient is ~0,
-    # e.g. k_proj.bias, only count through the pooled figures)
-    acc = {}
-    for n, g in ref.items():
-        d = got["grads"][n]
-        parts = n.split(".")
-        key = ".".join(parts[:3]) if parts[1] in ("video", "audio") else ".".join(parts[:2])
-        a = acc.setdefault(key, [0.0, 0.0, 0.0, 0.0])
-        a[0] += (d - g).pow(2).sum().item(); a[1] += g.pow(2).sum().item(); a[2] += d.pow(2).sum().item(); a[3] += (d * g).sum().item()
-    stats = {k: ((e / r) ** 0.5, (dd / r) ** 0.5, dg / (r * dd) ** 0.5) for k, (e, r, dd, dg) in acc.items()}
-    for k in sorted(stats):
-        print(f"  {k:40s} rel-err {stats[k][0]:.4f}  norm ratio {stats[k][1]:.4f}  cosine {stats[k][2]:.4f}")
-    # The two runs differ only by summation order (SyncBN's all-reduced fp32 sums vs one process's block sums, float
-    # atomics).  Audio tower and heads are well conditioned: a few 1e-3..1e-2.  The random-init train-mode-BatchNorm video
-    # trunk at this small shape is chaotic in its backward pass (two identical plain steps differ by several per cent,
-    # DESIGN.md "Numerics"): for it the check is the one a routing error cannot pass -- a factor of `world`, a rank's
-    # rows lost, a bucket reduced twice or never change the NORM of a stage's gradient by >= 30 % or decorrelate it.
-    # (measured: audio 0.3-1.1 %, video projection 3.5 %; trunk stages norm ratio 1.002-1.007, cosine 0.78-0.86)
-    H.set_deterministic(prev)
+    try:
+        # one process, the global batch, plain BatchNorm over all 2B clips (= what SyncBN computes across the two ranks)
+        net = _net(_cfg(False), layer_drop)
+        losses = []
+        for k, gb in enumerate(_batches(world, accumulate)):
+            loss, obj = _objective(net, gb.to("cuda"), k, world)
+            (obj / accumulate).backward()
+            losses.append(loss)
+        torch.cuda.synchronize()
+        print("losses", losses, got["loss"], "early hand-offs", got["pushed"])
+        assert got["pushed"] > 150
+        for a, b in zip(losses, got["loss"]):
+            assert abs(a - b) <= (1e-6 if det else 2e-3), (losses, got["loss"])
+        ref = {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None}
+        assert set(ref) == set(got["grads"]), set(ref) ^ set(got["grads"])      # same tensors skipped by LayerDrop / unused
+        if layer_drop > 0:
+            assert len(ref) < sum(1 for _ in net.parameters()) - 2              # (some layer was dropped in both micro-batches or fc)
+        # per group: pooled relative error, ratio of the pooled norms, pooled cosine (tensors whose true gradient is ~0,
+        # e.g. k_proj.bias, only count through the pooled figures)
+        acc = {}
+        for n, g in ref.items():
+            d = got["grads"][n]
+            parts = n.split(".")
+            key = ".".join(parts[:3]) if parts[1] in ("video", "audio") else ".".join(parts[:2])
+            a = acc.setdefault(key, [0.0, 0.0, 0.0, 0.0])
+            a[0] += (d - g).pow(2).sum().item(); a[1] += g.pow(2).sum().item(); a[2] += d.pow(2).sum().item(); a[3] += (d * g).sum().item()
+        stats = {k: ((e / r) ** 0.5, (dd / r) ** 0.5, dg / (r * dd) ** 0.5) for k, (e, r, dd, dg) in acc.items()}
+        for k in sorted(stats):
+            print(f"  {k:40s} rel-err {stats[k][0]:.4f}  norm ratio {stats[k][1]:.4f}  cosine {stats[k][2]:.4f}")
+        # The two runs differ only by summation order (SyncBN's all-reduced fp32 sums vs one process's block sums, float
+        # atomics).  Audio tower and heads are well conditioned: a few 1e-3..1e-2.  The random-init train-mode-BatchNorm video
+        # trunk at this small shape is chaotic in its backward pass (two identical plain steps differ by several per cent,
+        # DESIGN.md "Numerics"): for it the check is the one a routing error cannot pass -- a factor of `world`, a rank's
+        # rows lost, a bucket reduced twice or never change the NORM of a stage's gradient by >= 30 % or decorrelate it.
+        # (measured: audio 0.3-1.1 %, video projection 3.5 %; trunk stages norm ratio 1.002-1.007, cosine 0.78-0.86)
+    finally:
+        H.set_deterministic(prev)
     gmax = max(r for _, r, _, _ in acc.values())
     for k, (err, ratio, cos) in stats.items():
         if acc[k][1] < 1e-8 * gmax:

@@ -151,3 +151,65 @@ def test_triplet_pairing_and_geometry():
     assert clips[1].duration == 0.59 and clips[1].filename == "b.avi"
     trip = list(T.triplets([Clip(torch.zeros(1), torch.ones(1), 1.0, 2.0, "x"), Clip(torch.zeros(1), torch.ones(1), 1.1, 2.0, "y")]))
     assert len(trip) == 1 and isinstance(trip[0], T.Triplet)
+
+
+# ---- the build's correctness requirements are enforced, not trusted ------------------
+def test_shipped_code_objects_contain_no_packed_fp32():
+    """v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 return wrong results on gfx950 when MFMA-issuing
+    waves of another kernel share the SIMD (tools/probe/pk_mfma_min.hip).  Both shipped libraries are disassembled
+    (llvm-objdump -d on every gfx950 code object): no build recipe, ROCm upgrade or float2 expression may bring them back."""
+    from peppa_amd import build, _lib
+    for prec, path in _lib.LIB_PATHS.items():
+        assert os.path.exists(path), path
+        assert build.packed_fp32_instructions(path) == {}, (prec, build.packed_fp32_instructions(path))
+    # ... and the detector does see them where they exist (an object compiled without the flags)
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "pk.hip")
+        with open(src, "w") as f:
+            f.write("#include <hip/hip_runtime.h>\ntypedef float v2f __attribute__((ext_vector_type(2)));\n"
+                    "__global__ void k(v2f* p) { p[threadIdx.x] = p[threadIdx.x] * p[threadIdx.x + 64] + p[threadIdx.x + 128]; }\n")
+        obj = os.path.join(tmp, "pk.o")
+        subprocess.run([build.HIPCC, "--offload-arch=gfx950", "-O3", "-c", src, "-o", obj], check=True, capture_output=True)
+        assert build.packed_fp32_instructions(obj), "the detector must find v_pk_*_f32 in a float2 kernel built without the flags"
+        obj2 = os.path.join(tmp, "pk2.o")
+        subprocess.run([build.HIPCC] + build.FLAGS + ["-c", src, "-o", obj2], check=True, capture_output=True)
+        assert build.packed_fp32_instructions(obj2) == {}, "the build flags must keep even explicit float2 arithmetic scalar"
+
+
+def test_shipped_libraries_are_not_experiment_builds():
+    from peppa_amd import _lib
+    for prec in _lib.LIB_PATHS:
+        assert _lib.lib(prec).pp_experimental_build() == 0
+
+
+def test_build_staleness_covers_flags_and_compiler(tmp_path):
+    from peppa_amd import build
+    obj, src = tmp_path / "a.o", tmp_path / "a.hip"
+    src.write_text("x")
+    obj.write_text("o")
+    cmd = ["hipcc", "-O3", "-c", str(src)]
+    assert build._stale(str(obj), [str(src)], build._stamp(cmd))            # no stamp yet: a build/ that predates the stamps
+    (tmp_path / "a.o.stamp").write_text(build._stamp(cmd))
+    assert not build._stale(str(obj), [str(src)], build._stamp(cmd))
+    assert build._stale(str(obj), [str(src)], build._stamp(cmd + ["-fno-slp-vectorize"]))   # a flag change rebuilds
+    with pytest.raises(RuntimeError):
+        build.build_library(extra_flags=["-DPP_TW_ABLATE=15"])             # never into the shipped library
+
+
+def test_bertadam_scratch_is_size_checked():
+    from peppa_amd import hip as H
+    from peppa_amd._lib import TensorList, PeppaHipError
+    tl = TensorList()
+    tl.n_tensors = 5
+    prev = H.DETERMINISTIC
+    try:
+        H.DETERMINISTIC = True     # the flag alone: the check runs before any device call
+        with pytest.raises(PeppaHipError, match="norms"):
+            H.bertadam_step(tl, None, None, 12, 16, torch.empty(5), 1e-3, 0.9, 0.999, 1e-6, 0.01, 1.0)
+        H.DETERMINISTIC = False
+        with pytest.raises(PeppaHipError, match="norms"):
+            H.bertadam_step(tl, None, None, 12, 16, torch.empty(4), 1e-3, 0.9, 0.999, 1e-6, 0.01, 1.0)
+    finally:
+        H.DETERMINISTIC = prev

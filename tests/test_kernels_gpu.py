@@ -638,7 +638,7 @@ def test_bertadam_golden(golden_dir):
             co.append(off)
     ctd = torch.tensor(ct, dtype=torch.int32, device=DEV)
     cod = torch.tensor(co, dtype=torch.int64, device=DEV)
-    norms = torch.empty(5, device=DEV)
+    norms = torch.empty(5 + len(ct), device=DEV)    # [tensors] + [chunks]: the deterministic mode's per-chunk partials
     from oracle.model import warmup_linear
     for step in range(6):
         for i in range(5):
