@@ -62,7 +62,9 @@ int pp_experimental_build(void);
  *                      (default 0; an A/B switch from the investigation in DESIGN.md section 7)
  *   "win_out_nt"   0/1 non-temporal stores of the window kernels' output tiles (default 1)
  *   "bn_nt" b, "bn_grid" n   BatchNorm streaming passes: non-temporal loads (bit 0) / stores (bit 1), workgroups per launch
- *   "persist_cus"  n   workgroups of the persistent ring / window kernels (8..256, default 256 = one per CU) */
+ *   "persist_cus"  n   workgroups of the persistent ring / window kernels (8..256, default 256 = one per CU)
+ *   "wgrad_flat"   0/1 grouped weight gradients (pp_wgrad_desc.ptr_table) walk (problem, tile) as one flat grid in
+ *                      slab-sharing order (default 1; 0 = one problem per grid.z slice, round 3's order) */
 int pp_set_option(const char* name, int value);
 const char* pp_last_error(void);
 
@@ -283,17 +285,18 @@ int pp_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
                      void* dx, float* dgamma, float* dbeta, int rows, int D, float* ws, int ws_blocks, pp_stream_t s);
 
 /* ---- softmax over attention scores (SelfAttention in wav2vec2) ------------------------- */
-/* Fused attention core of torchaudio's SelfAttention (T <= 256 frames, 64-wide heads): qkv bf16 [B*T][3*heads*64]
+/* Fused attention core of torchaudio's SelfAttention (T <= 320 frames, 64-wide heads): qkv bf16 [B*T][3*heads*64]
  * (q | k | v), ctx / dctx bf16 [B*T][heads*64], dqkv like qkv.  ctx = dropout(softmax(scale * q k^T)) v per (clip, head);
  * the backward recomputes the probabilities and regenerates the dropout mask from (seed, element index of the
  * [B*heads][T][Tp] probability tensor, Tp = T rounded up to 16) -- the same stream pp_dropout_bf16 would use. */
 int pp_attention_fwd(const void* qkv, int B, int T, int heads, float scale, float drop_p, unsigned seed, void* ctx,
                      float* lse /* out: [B*heads][T] log-sum-exp of the scaled scores, kept for the backward pass */,
                      pp_stream_t s);
-/* ctx = the forward's output, lse = its log-sum-exp rows; T <= 256 (128 < T <= 256: 2 x 2 blocks of 128 in one workgroup) */
+/* ctx = the forward's output, lse = its log-sum-exp rows; T <= 320 (T > 128: 2 x 2 or 3 x 3 blocks of 128 in one workgroup) */
 int pp_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx, int B, int T, int heads,
                      float scale, float drop_p, unsigned seed, void* dqkv, pp_stream_t s);
-/* S fp32 [nb][T][lds] -> P bf16 [nb][T][ldp], P = softmax(scale*S) over T cols, pad cols = 0 */
+/* S fp32 [nb][T][lds] -> P bf16 [nb][T][ldp], P = softmax(scale*S) over T cols, pad cols = 0; T <= ldp <= 1024 (the unfused
+ * attention path of clips beyond the fused kernels' 320 frames) */
 int pp_softmax_fwd(const float* S, int lds, void* P, int ldp, int nb, int T, float scale, pp_stream_t s);
 /* dS bf16 [nb][T][ldp] = scale * P * (dP - sum_j P*dP); dP fp32 [nb][T][lds] */
 int pp_softmax_bwd(const float* dP, int lds, const void* P, int ldp, void* dS, int nb, int T, float scale,

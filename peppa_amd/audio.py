@@ -271,8 +271,8 @@ def _build_encoder_weights(enc, save):
     return w, batch
 
 
-FUSED_ATTENTION = True   # one launch per direction (pp_attention_*) when T <= 256; False: batched GEMMs + softmax + transposes
-FUSED_ATTENTION_MAX_T = 256
+FUSED_ATTENTION = True   # one launch per direction (pp_attention_*) when T <= 320; False: batched GEMMs + softmax + transposes
+FUSED_ATTENTION_MAX_T = 320     # (316 frames = the reference's own 2.3-s clips at 44.1 kHz; longer clips take the unfused path, T <= 1024)
 
 
 def _attention_fwd(qkv, B, T, Tp, scale, save, drop=(0.0, 0)):

@@ -1,8 +1,9 @@
-// Fused self-attention core of the wav2vec2 encoder layers (torchaudio SelfAttention, T <= 256 frames, 64-wide heads),
-// forward and backward -- gfx950.  T <= 128: one workgroup per (clip, head), as described below.  128 < T <= 256 (the
-// 229 frames of 4.6-s clips, BASELINE configs[4]): the forward runs one workgroup per (clip, head, 64 query rows) against
-// all keys; the backward walks the 2 x 2 blocks of 128 queries x 128 keys inside one workgroup, with the softmax
-// normalisation taken from the forward's log-sum-exp (lse) and D = rowsum(dO o O) instead of in-kernel row statistics.
+// Fused self-attention core of the wav2vec2 encoder layers (torchaudio SelfAttention, T <= 320 frames, 64-wide heads),
+// forward and backward -- gfx950.  T <= 128: one workgroup per (clip, head), as described below.  128 < T <= 320 (the
+// 229 frames of 4.6-s clips, BASELINE configs[4]; the 316 frames of the reference's own 2.3-s clips at 44.1 kHz fed
+// unresampled): the forward runs one workgroup per (clip, head, 64 query rows) against all keys (256 or 320
+// key rows in LDS); the backward walks the NB x NB blocks of 128 queries x 128 keys inside one workgroup (NB = 2, 3), with the
+// softmax normalisation taken from the forward's log-sum-exp (lse) and D = rowsum(dO o O) instead of in-kernel row statistics.
 //
 //   forward : S = scale * Q K^T -> P = softmax(S) -> Pd = dropout(P) -> O = Pd V
 //   backward: recomputes S, P, Pd from Q, K (nothing is saved but the dropout seed), then
@@ -160,10 +161,12 @@ __device__ __forceinline__ void store_t(h16raw* out, long long ld, int row, int 
 }
 
 // Forward: four waves, 16 MT query rows each, against all 16 NT keys.  <2, 8>: T <= 128, one workgroup per (clip, head).
-// <1, 16>: T <= 256, one workgroup per (clip, head, 64 query rows) -- K and V of the head are loaded by each of them (L2).
+// <1, 16> / <1, 20>: T <= 256 / 320, one workgroup per (clip, head, 64 query rows) -- K and V of the head are loaded by each of
+// them (L2); 320 key rows are what fits: (64 + 2 x 320) x 160 B of Q, K, V + 64 x 672 B of probabilities = 152 KB.
 template <int MT, int NT>
 __global__ __launch_bounds__(256, 1) void attention_fwd_kernel(const AttnArgs p) {
   constexpr int QB = 64 * MT, KR = 16 * NT, PS = ps_of<NT>();
+  static_assert((QB + 2 * KR) * QS + QB * PS <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[(QB + 2 * KR) * QS + QB * PS];
   unsigned char* Qs = smem;
   unsigned char* Ks = smem + QB * QS;
@@ -321,6 +324,9 @@ __global__ __launch_bounds__(BNT, 1) void attention_bwd_kernel(const AttnArgs p)
           if (NB == 1 || kb == 0) {
             accV[0][nd] = PP_MFMA16(ao, bp, accV[0][nd], 0, 0, 0);
             accK[0][nd] = PP_MFMA16(aq, bs, accK[0][nd], 0, 0, 0);
+          } else if (NB == 2 || kb == 1) {
+            accV[1 < NB ? 1 : 0][nd] = PP_MFMA16(ao, bp, accV[1 < NB ? 1 : 0][nd], 0, 0, 0);
+            accK[1 < NB ? 1 : 0][nd] = PP_MFMA16(aq, bs, accK[1 < NB ? 1 : 0][nd], 0, 0, 0);
           } else {
             accV[NB - 1][nd] = PP_MFMA16(ao, bp, accV[NB - 1][nd], 0, 0, 0);
             accK[NB - 1][nd] = PP_MFMA16(aq, bs, accK[NB - 1][nd], 0, 0, 0);
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(BNT, 1) void attention_bwd_kernel(const AttnArgs p)
 }
 
 int check(const char* who, const void* qkv, int B, int T, int Hn, float p) {
-  PP_CHECK_ARG(qkv && B > 0 && T > 0 && T <= 256 && Hn > 0 && Hn <= 64, "%s: B=%d T=%d heads=%d unsupported (T <= 256)", who, B, T, Hn);
+  PP_CHECK_ARG(qkv && B > 0 && T > 0 && T <= 320 && Hn > 0 && Hn <= 64, "%s: B=%d T=%d heads=%d unsupported (T <= 320)", who, B, T, Hn);
   PP_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout p=%f", who, (double)p);
   return PP_OK;
 }
@@ -376,7 +382,8 @@ extern "C" int pp_attention_fwd(const void* qkv, int B, int T, int heads, float 
     hipLaunchKernelGGL((attention_fwd_kernel<2, 8>), dim3(B * heads), dim3(256), 0, (hipStream_t)s, a);
   } else {
     a.nqb = (T + 63) / 64;
-    hipLaunchKernelGGL((attention_fwd_kernel<1, 16>), dim3(B * heads * a.nqb), dim3(256), 0, (hipStream_t)s, a);
+    if (T <= 256) hipLaunchKernelGGL((attention_fwd_kernel<1, 16>), dim3(B * heads * a.nqb), dim3(256), 0, (hipStream_t)s, a);
+    else hipLaunchKernelGGL((attention_fwd_kernel<1, 20>), dim3(B * heads * a.nqb), dim3(256), 0, (hipStream_t)s, a);
   }
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -392,7 +399,8 @@ extern "C" int pp_attention_bwd(const void* qkv, const void* ctx, const float* l
   a.lse = (float*)lse;
   a.dqkv = (h16raw*)dqkv;
   if (T <= 128) hipLaunchKernelGGL((attention_bwd_kernel<1>), dim3(B * heads), dim3(BNT), 0, (hipStream_t)s, a);
-  else hipLaunchKernelGGL((attention_bwd_kernel<2>), dim3(B * heads), dim3(BNT), 0, (hipStream_t)s, a);
+  else if (T <= 256) hipLaunchKernelGGL((attention_bwd_kernel<2>), dim3(B * heads), dim3(BNT), 0, (hipStream_t)s, a);
+  else hipLaunchKernelGGL((attention_bwd_kernel<3>), dim3(B * heads), dim3(BNT), 0, (hipStream_t)s, a);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

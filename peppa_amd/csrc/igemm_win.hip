@@ -57,7 +57,8 @@ __device__ unsigned long long pp_win_stamp_buf[256 * 8 * 8];
 #endif
 constexpr int BK = 64;
 constexpr int NW = 8, NT = 64 * NW;
-constexpr int HALO = 64;                      // rows kept on either side of the tile (>= W + 1)
+constexpr int HALO = 64;                      // rows kept on either side of the tile (>= W + 1); template HL = 96: frames up to
+                                              // 95 wide (the reference's own 100 x 180 clips: layer 1 is 50 x 90)
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -192,7 +193,7 @@ struct WinArgs {
 // PROD = four producer waves (8, 9: weights; 10, 11: windows) issue every LDS-DMA and do nothing else; the eight
 // multiplying waves issue none and never wait on vmcnt (wgrad_tw.hip measured why: a wave that multiplies is not at its
 // DMA instructions when the memory pipeline has room for them).  Twelve waves = three per SIMD = 168 registers each.
-template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false, bool STG = false, bool PROD = false>
+template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false, bool STG = false, bool PROD = false, int HL = HALO>
 __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap, const int out_nt) {
   constexpr int BM = 16 * MT * NW;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   constexpr bool TRC = PP_WIN_TRANSPOSED_ACC && !BNR;
   // temporal tiles with narrow outputs: no halo rows at all and THREE window buffers -- the window of the phase after
   // next is in flight too, because a phase (3 short K-steps) is far shorter than an HBM round trip
-  constexpr int HALO_ = (TW && WN <= 4) ? 0 : HALO;
+  constexpr int HALO_ = (TW && WN <= 4) ? 0 : HL;
   constexpr int NWIN = (TW && WN <= 4) ? 3 : 2;
   constexpr int D = NWIN - 1;                                 // phases of window look-ahead
   constexpr int WROWS = BM + 2 * HALO_;
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 template <int WN, int CC, int MT, bool TW>
 constexpr bool bnr_built() { return TW ? (CC == 64 && WN == 4) : (WN == 4 || WN == 8); }   // (MT x NIT <= 8 chunks of y per lane)
 
-template <int WN, int CC, int MT, int NBS, bool TW = false>
+template <int WN, int CC, int MT, int NBS, bool TW = false, int HL = HALO>
 int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   constexpr int BN = 16 * WN, BM = 16 * MT * NW;
   const pp_gather& gg = d.g;
@@ -1058,6 +1059,16 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
+  if constexpr (!TW && HL != HALO) {
+    // frames wider than 63 (HL = 96 rows of halo): the producer form only -- no BatchNorm-backward sums in the epilogue
+    // (the caller runs pp_bn_bwd_reduce: PP_BNR_SKIPPED), no staggered / lockstep variants
+    if (bna) { pp_set_error("pp_igemm: fused BatchNorm apply is built for the temporal window kernel only"); return PP_ERR_INVALID; }
+    dim3 pblock(NT + 256);
+    if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, true, HL>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+    else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, true, HL>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+    PP_LAUNCH_CHECK();
+    return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
+  } else {
   if constexpr (TW) {
     if (pp_opt_win_producers >= 3 && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {     // (3: also the temporal form)
       dim3 pblock(NT + 256);
@@ -1118,6 +1129,7 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
   PP_LAUNCH_CHECK();
   return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
+  }
 }
 
 }  // namespace
@@ -1164,13 +1176,26 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
     if (g.cg == 144 && n16 <= 4) return launch_win<4, 48, 2, 9, true>(d, s);
     return 1;
   }
+  constexpr int HALO_WIDE = 96;
   const bool shape_ok = conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre && !d.omap && d.drop_p == 0.f &&
                         g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 &&
-                        g.ph == 1 && g.pw == 1 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && g.Gw + 1 <= HALO &&
+                        g.ph == 1 && g.pw == 1 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && g.Gw + 1 <= HALO_WIDE &&
                         d.K == 9 * g.cg && (g.cg % 64 == 0 || g.cg % 48 == 0) &&
                         (long long)d.M * g.cstride < 0x7f000000LL && (!d.residual || d.ldr % 8 == 0);
   if (!shape_ok) return 1;
   const int n16 = (d.N + 15) / 16;
+  if (g.Gw + 1 > HALO) {
+    // frames 64..95 wide (the reference's own clips: layer 1 is 50 x 90): 96 rows of halo.  Two (256 + 192)-row windows of
+    // 64-channel rows are 112 KB, so the wide tiles keep a TWO-slot weight ring (one K-step of flight for a weight slice);
+    // the 48-channel data gradient keeps 256-row tiles (the 512-row tile's windows would be 154 KB)
+    const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
+    if (g.cg % 64 == 0) {
+      if (n16 <= 4) return launch_win<4, 64, 2, 3, false, HALO_WIDE>(d, s);
+      return c9 <= c8 ? launch_win<9, 64, 2, 2, false, HALO_WIDE>(d, s) : launch_win<8, 64, 2, 2, false, HALO_WIDE>(d, s);
+    }
+    if (n16 <= 4) return launch_win<4, 48, 2, 3, false, HALO_WIDE>(d, s);
+    return c9 <= c8 ? launch_win<9, 48, 2, 2, false, HALO_WIDE>(d, s) : launch_win<8, 48, 2, 2, false, HALO_WIDE>(d, s);
+  }
   // tile widths: 64 columns (narrow outputs) or 128 / 144 (whichever pads N less)
   if (g.cg % 64 == 0) {
     if (n16 <= 4) return launch_win<4, 64, 2, 3>(d, s);

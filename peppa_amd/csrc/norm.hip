@@ -208,17 +208,19 @@ __global__ __launch_bounds__(256) void ln_bwd_partials_kernel(const float* __res
   }
 }
 
-constexpr int SM_MAXC = 4;  // columns per lane -> T <= 256
+constexpr int SM_MAXC = 16;  // columns per lane, template SMC = 4 / 8 / 16 -> T <= 256 / 512 / 1024 (the unfused attention path:
+                            // clips beyond the fused kernel's 320 frames, e.g. > 2.3 s of 44.1-kHz audio fed unresampled)
 
+template <int SMC>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, int lds, h16raw* __restrict__ P, int ldp,
                                                           long long rows, int T, float scale) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  float v[SM_MAXC];
+  float v[SMC];
   float mx = -3.0e38f;
 #pragma unroll
-  for (int c = 0; c < SM_MAXC; ++c) {
+  for (int c = 0; c < SMC; ++c) {
     const int j = lane + 64 * c;
     v[c] = j < T ? S[row * lds + j] * scale : -3.0e38f;
     mx = fmaxf(mx, v[c]);
@@ -226,28 +228,29 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
   mx = wave_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int c = 0; c < SM_MAXC; ++c) {
+  for (int c = 0; c < SMC; ++c) {
     const int j = lane + 64 * c;
     v[c] = j < T ? __expf(v[c] - mx) : 0.f;
     sum += v[c];
   }
   const float inv = 1.f / wave_sum(sum);
 #pragma unroll
-  for (int c = 0; c < SM_MAXC; ++c) {
+  for (int c = 0; c < SMC; ++c) {
     const int j = lane + 64 * c;
     if (j < ldp) P[row * ldp + j] = f2h(v[c] * inv);
   }
 }
 
+template <int SMC>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dP, int lds, const h16raw* __restrict__ P,
                                                           int ldp, h16raw* __restrict__ dS, long long rows, int T, float scale) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  float p[SM_MAXC], d[SM_MAXC];
+  float p[SMC], d[SMC];
   float dot = 0.f;
 #pragma unroll
-  for (int c = 0; c < SM_MAXC; ++c) {
+  for (int c = 0; c < SMC; ++c) {
     const int j = lane + 64 * c;
     p[c] = j < T ? h2f(P[row * ldp + j]) : 0.f;
     d[c] = j < T ? dP[row * lds + j] : 0.f;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
   dot = wave_sum(dot);
 #pragma unroll
-  for (int c = 0; c < SM_MAXC; ++c) {
+  for (int c = 0; c < SMC; ++c) {
     const int j = lane + 64 * c;
     if (j < ldp) dS[row * ldp + j] = f2h(scale * p[c] * (d[c] - dot));
   }
@@ -510,7 +513,10 @@ extern "C" int pp_layernorm_bwd(const void* dy, const void* x, const float* gamm
 extern "C" int pp_softmax_fwd(const float* S, int lds, void* P, int ldp, int nb, int T, float scale, pp_stream_t s) {
   PP_CHECK_ARG(nb > 0 && T > 0 && T <= 64 * SM_MAXC && ldp >= T && ldp <= 64 * SM_MAXC && lds >= T, "pp_softmax_fwd: T=%d ldp=%d unsupported", T, ldp);
   const long long rows = (long long)nb * T;
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_, S, lds, (h16raw*)P, ldp, rows, T, scale);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (ldp <= 256) hipLaunchKernelGGL(softmax_fwd_kernel<4>, grid, block, 0, S_, S, lds, (h16raw*)P, ldp, rows, T, scale);
+  else if (ldp <= 512) hipLaunchKernelGGL(softmax_fwd_kernel<8>, grid, block, 0, S_, S, lds, (h16raw*)P, ldp, rows, T, scale);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<16>, grid, block, 0, S_, S, lds, (h16raw*)P, ldp, rows, T, scale);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -518,8 +524,10 @@ extern "C" int pp_softmax_bwd(const float* dP, int lds, const void* P, int ldp, 
                               pp_stream_t s) {
   PP_CHECK_ARG(nb > 0 && T > 0 && T <= 64 * SM_MAXC && ldp >= T && ldp <= 64 * SM_MAXC && lds >= T, "pp_softmax_bwd: T=%d ldp=%d unsupported", T, ldp);
   const long long rows = (long long)nb * T;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_, dP, lds, (const h16raw*)P, ldp,
-                     (h16raw*)dS, rows, T, scale);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (ldp <= 256) hipLaunchKernelGGL(softmax_bwd_kernel<4>, grid, block, 0, S_, dP, lds, (const h16raw*)P, ldp, (h16raw*)dS, rows, T, scale);
+  else if (ldp <= 512) hipLaunchKernelGGL(softmax_bwd_kernel<8>, grid, block, 0, S_, dP, lds, (const h16raw*)P, ldp, (h16raw*)dS, rows, T, scale);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<16>, grid, block, 0, S_, dP, lds, (const h16raw*)P, ldp, (h16raw*)dS, rows, T, scale);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

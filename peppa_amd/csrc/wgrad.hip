@@ -12,6 +12,7 @@
 
 int pp_validate_gather(const pp_gather& g, int K, const char* who);
 extern int pp_opt_xcd_remap_wgrad;
+extern int pp_opt_wgrad_flat;
 extern int pp_opt_ring_wgrad;
 extern int pp_opt_sw_wgrad;
 extern int pp_opt_deterministic;
@@ -49,7 +50,8 @@ __device__ __forceinline__ h16x8 tr_frag(const unsigned char* tile, int stride, 
 template <int WI, int MODE, bool BIAS>
 __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_wgrad_desc p, const WGeom wg,
                                                                         const int nblk_i, const int nblk_j,
-                                                                        const int rows_per_split, const int xcd_remap) {
+                                                                        const int rows_per_split, const int xcd_remap,
+                                                                        const int flat) {
   constexpr int TI = 16 * WI;
   constexpr int PS = (WI & 1) ? TI * 2 : TI * 2 + 32;  // P row stride (bytes), 32*odd
   constexpr int P_BYTES = MS * PS;
@@ -71,17 +73,33 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
     const int xq = nwg >> 3, xr = nwg & 7, xcd = b0 & 7;
     bid = xcd_remap ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b0 >> 3) : b0;
   }
-  const int ib = bid % nblk_i; bid /= nblk_i;
-  const int jb = bid % nblk_j; bid /= nblk_j;
-  const int split = bid;
-  const int z = blockIdx.z;
+  // `flat` (grouped launches without an M split): the grid is ONE dimension over (problem, tile) and an XCD walks a
+  // contiguous run of it in which the index of the SHORTER tile axis runs fastest.  A tile streams two M x 128 slabs (dY
+  // columns of its ib, X columns of its jb); tiles that run together on one XCD share them through its L2.  With ib
+  // fastest and one problem's tiles dealt over all eight XCDs (the order below, round 3) every dY slab of ffn1 (24 x 6
+  // tiles) was fetched by six XCDs: 3.64 GB for 0.79 GB of operands (profiles/r03_pmc_traffic.md).  Here the tiles that share
+  // the slab of the LONGER axis (the big operand) are neighbours on one XCD and fetch it once; the slabs of the shorter axis
+  // (the small operand) are re-fetched once per round of resident workgroups.
+  int ib, jb, split, z;
+  if (flat) {
+    const int tiles = nblk_i * nblk_j;
+    z = bid / tiles;
+    const int r = bid - z * tiles;
+    if (nblk_j <= nblk_i) { jb = r % nblk_j; ib = r / nblk_j; } else { ib = r % nblk_i; jb = r / nblk_i; }
+    split = 0;
+  } else {
+    ib = bid % nblk_i; bid /= nblk_i;
+    jb = bid % nblk_j; bid /= nblk_j;
+    split = bid;
+    z = blockIdx.z;
+  }
   const h16raw* X = (const h16raw*)p.X + z * p.x_s;
   const h16raw* dY = (const h16raw*)p.dY + z * p.dy_s;
   float* __restrict__ dW = p.dW + z * p.dw_s;
   float* dbias_z = BIAS ? p.dbias + z * p.dbias_s : nullptr;
   // deterministic mode: this (problem, split)'s slab of p.ws -- Ni rows of ldw floats, then Ni bias floats
   const long long slab_floats = (long long)p.Ni * p.ldw + p.Ni;
-  const long long slab_w = ((long long)z * (gridDim.x / (nblk_i * nblk_j)) + split) * slab_floats;
+  const long long slab_w = ((long long)z * (flat ? 1 : gridDim.x / (nblk_i * nblk_j)) + split) * slab_floats;
   const long long slab_b = slab_w + (long long)p.Ni * p.ldw;
   if (p.ptr_table) {      // grouped launch: problem z has its own operands (uniform scalar loads)
     const unsigned long long* e = p.ptr_table + 4 * z;
@@ -702,7 +720,9 @@ int launch_wi(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query = nullp
   wg.dRh = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rh));
   wg.dRt = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rt));
   const long long gx = (long long)nblk_i * nblk_j * msplit;
-  dim3 grid((unsigned)gx, 1, (unsigned)d.nbatch), block(256);
+  // grouped problems without an M split: one flat grid in slab-sharing order (see the kernel)
+  const int flat = (pp_opt_wgrad_flat && d.ptr_table && msplit == 1 && gx * d.nbatch < 0x7fffffffLL) ? 1 : 0;
+  dim3 grid((unsigned)(flat ? gx * d.nbatch : gx), 1, (unsigned)(flat ? 1 : d.nbatch)), block(256);
   pp_wgrad_desc k = d;                       // what the kernel sees: ws only when this launch really is split
   const bool slabs = pp_opt_deterministic && msplit > 1;
   if (ws_query) { *ws_query = slabs ? slab_floats_total(d, msplit) : 0; return PP_OK; }
@@ -713,10 +733,10 @@ int launch_wi(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query = nullp
     k.ws = nullptr;
   }
   if (d.g.mode == PP_DENSE) {
-    if (d.dbias) hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, true>), grid, block, 0, s, k, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
-    else hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, false>), grid, block, 0, s, k, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+    if (d.dbias) hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, true>), grid, block, 0, s, k, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad, flat);
+    else hipLaunchKernelGGL((wgrad_kernel<WI, PP_DENSE, false>), grid, block, 0, s, k, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad, flat);
   } else {
-    hipLaunchKernelGGL((wgrad_kernel<WI, PP_CONV_FWD, false>), grid, block, 0, s, k, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+    hipLaunchKernelGGL((wgrad_kernel<WI, PP_CONV_FWD, false>), grid, block, 0, s, k, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad, flat);
   }
   if (slabs) launch_slab_sum(d, msplit, s);
   PP_LAUNCH_CHECK();

@@ -9,6 +9,8 @@
 //     (36 column tiles of 16; twelve waves, three tiles each -> 108 accumulator registers per lane);
 //   * per 64-row step it fetches 64 new rows of X (8 KB) and the 64 x TI slab of dY, by LDS-DMA, three steps
 //     ahead (512-row ring for X, three slots for dY, counted vmcnt across raw barriers as in igemm.hip's ring);
+//     a step reads X rows up to W + 1 before / after its own 64: one 64-row group on either side (XA = 1, W <= 63) or two
+//     (XA = 2, W <= 127: the reference's own 100 x 180 clips are 50 x 90 at layer 1) -- the X stream then runs a group further ahead;
 //   * the nine taps are nine row-shifted views of the window: the transposing LDS reads (ds_read_b64_tr_b16) take
 //     per-lane row addresses, so a shift is an address offset.  Rows whose tap falls outside the image (the window
 //     holds the neighbouring row / frame there) are cleared with a 16-bit AND mask per (row, tap), which one wave
@@ -76,7 +78,7 @@ struct SwGeom {
   int cg;             // channels per tap in dW's layout (= padded Ci)
 };
 
-template <int WI>
+template <int WI, int XA>
 __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const h16raw* __restrict__ X, const h16raw* __restrict__ dY,
                                                           float* __restrict__ dW, const SwGeom g, const int Ni,
                                                           const int ldy, const int ldw, const int nblk_i,
@@ -139,11 +141,11 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const h16raw* __restric
     }
   }
   npiece = __builtin_amdgcn_readfirstlane(npiece);
-  // issue this wave's pieces of step `st` (dY rows of the step, X rows of group st + 1 relative to the step);
+  // issue this wave's pieces of step `st` (dY rows of the step, X rows of group st + XA relative to the step);
   // steps outside [0, nsteps) and rows outside the tensor fetch zeros
   auto dma_step = [&](const int st) __attribute__((always_inline)) {
     const int mP = m_begin + st * MS;              // first dY row of the step
-    const int mX = mP + MS;                        // first row of the X group that step st brings in (one ahead)
+    const int mX = mP + XA * MS;                   // first row of the X group that step st brings in (XA groups ahead)
     unsigned char* const pdst = pring + (st % NPSLOT) * P_BYTES;
     unsigned char* const xdst = xwin + ((mX & (XROWS - 1)) * XS);
 #pragma unroll
@@ -257,10 +259,10 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const h16raw* __restric
     }
   };
 
-  // ---- prologue: dma_step(st) brings dY step st and X group st + 1 (step st reads groups st - 1 .. st + 1), so the
-  // X stream starts two groups early: groups -1 and 0 alone, then steps 0 and 1; masks of step 0 ---------------------
-  auto dma_x_only = [&](const int st) __attribute__((always_inline)) {   // X group st + 1 only (prologue)
-    const int mX = m_begin + (st + 1) * MS;
+  // ---- prologue: dma_step(st) brings dY step st and X group st + XA (step st reads groups st - XA .. st + XA), so the
+  // X stream starts 2 XA groups early: groups -XA .. XA - 1 alone, then steps 0 and 1; masks of step 0 -----------------
+  auto dma_x_only = [&](const int grp) __attribute__((always_inline)) {   // X group `grp` only (prologue)
+    const int mX = m_begin + grp * MS;
     unsigned char* const xdst = xwin + ((mX & (XROWS - 1)) * XS);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const h16raw* __restric
       }
     }
   };
-  dma_x_only(-2);
-  dma_x_only(-1);
+#pragma unroll
+  for (int grp = -XA; grp < XA; ++grp) dma_x_only(grp);
   dma_step(0);
   dma_step(1);
   if (wave == 0) make_masks(0);
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_sw_kernel(const h16raw* __restric
   }
 }
 
-template <int WI>
+template <int WI, int XA>
 int launch_sw(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query) {
   const pp_gather& gg = d.g;
   SwGeom g;
@@ -349,7 +351,7 @@ int launch_sw(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query) {
   const long long need = slabs ? (long long)msplit * d.Ni * d.ldw : 0;
   if (ws_query) { *ws_query = need; return PP_OK; }
   if (slabs) PP_CHECK_ARG(d.ws && d.ws_floats >= need, "pp_wgrad: deterministic mode needs ws of pp_wgrad_ws_floats(d) = %lld floats", need);
-  hipLaunchKernelGGL((wgrad_sw_kernel<WI>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
+  hipLaunchKernelGGL((wgrad_sw_kernel<WI, XA>), grid, block, 0, s, (const h16raw*)d.X, (const h16raw*)d.dY, d.dW, g, d.Ni, d.ldy,
                      d.ldw, nblk_i, nblk_c, rows_per_split, pp_opt_xcd_remap_wgrad, slabs ? d.ws : (float*)nullptr);
   if (slabs) pp_wgrad_slab_sum(d.ws, msplit, (long long)d.Ni * d.ldw, d.Ni, d.Kj, d.ldw, d.dW, s);
   PP_LAUNCH_CHECK();
@@ -364,10 +366,11 @@ int pp_wgrad_sw_try(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query) 
   const pp_gather& g = d.g;
   const bool shape_ok = g.mode == PP_CONV_FWD && d.nbatch == 1 && !d.dbias && g.kt == 1 && g.kh == 3 && g.kw == 3 &&
                         g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 && g.ph == 1 && g.pw == 1 && g.Gt == g.Rt &&
-                        g.Gh == g.Rh && g.Gw == g.Rw && g.Gw + 1 <= MS && g.cg % 64 == 0 && d.Kj == 9 * g.cg &&
+                        g.Gh == g.Rh && g.Gw == g.Rw && g.Gw + 1 <= 2 * MS && g.cg % 64 == 0 && d.Kj == 9 * g.cg &&
                         d.Ni >= 128 && (long long)d.M * g.cstride < 0x7fffffffLL && (long long)d.M * d.ldy < 0x7fffffffLL;
   if (!shape_ok) return 1;
   const int n16 = (d.Ni + 15) / 16;
   const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
-  return c9 <= c8 ? launch_sw<9>(d, s, ws_query) : launch_sw<8>(d, s, ws_query);
+  if (g.Gw + 1 > MS) return c9 <= c8 ? launch_sw<9, 2>(d, s, ws_query) : launch_sw<8, 2>(d, s, ws_query);   // frames 64..127 wide
+  return c9 <= c8 ? launch_sw<9, 1>(d, s, ws_query) : launch_sw<8, 1>(d, s, ws_query);
 }

@@ -858,8 +858,11 @@ def test_ring_wgrad_matches_register_staged(case):
     (128, 288, 2, 2, 14, 13),     # two channel blocks x two row blocks, odd width
     (64, 128, 1, 5, 9, 56),       # 128-row block (8 tiles), the layer-1 width
     (192, 230, 1, 2, 7, 7),       # ragged rows of dW (230 of 240), three channel blocks, tiny image (window >> image)
-    (64, 144, 1, 2, 3, 63),       # widest supported image (W + 1 = one 64-row step)
+    (64, 144, 1, 2, 3, 63),       # widest image of the one-group form (W + 1 = one 64-row step)
     (64, 144, 1, 1, 5, 7),        # fewer rows than one step
+    (64, 144, 1, 2, 7, 90),       # the reference's own layer-1 width (100 x 180 clips): two 64-row groups on either side
+    (128, 288, 1, 1, 3, 127),     # widest supported image (W + 1 = two steps)
+    (64, 144, 1, 1, 4, 64),       # first width of the two-group form
 ])
 def test_sliding_window_wgrad_matches_generic(case):
     """Sliding-window weight gradient (X window in LDS, taps = row-shifted views + border masks) against the generic
@@ -897,8 +900,12 @@ def test_sliding_window_wgrad_matches_generic(case):
     (64, 230, 1, 3, 9, 56),       # dgrad from 240 padded channels (five 48-channel chunks); layer-1 width
     (256, 576, 1, 1, 14, 14),     # dgrad with 64-channel chunks (576 = 9 x 64); window >> image
     (64, 128, 3, 1, 7, 5),        # tiny images: most of every window lies in neighbouring images; ragged last tile
-    (144, 64, 1, 2, 3, 63),       # widest supported image (W + 1 = halo); fwd from 48-channel chunks to 64 columns
+    (144, 64, 1, 2, 3, 63),       # widest image of the 64-row halo (W + 1 = halo); fwd from 48-channel chunks to 64 columns
     (64, 144, 1, 1, 4, 9),        # a single partial tile (36 rows)
+    (64, 144, 1, 2, 7, 90),       # the reference's own layer-1 width (100 x 180 clips): 96-row halo, two-slot weight ring
+    (144, 64, 1, 1, 5, 95),       # widest supported image (W + 1 = 96); fwd 48-channel chunks -> 64 columns, dgrad 64 -> 144
+    (128, 128, 1, 1, 4, 64),      # first width of the 96-row halo; 128-column tiles both ways
+    (64, 45, 1, 1, 6, 70),        # narrow output from 64-channel chunks; dgrad from 48 padded channels
 ])
 def test_window_igemm_matches_gather_igemm(case):
     """Window conv kernel (A halo window in LDS, taps = address offsets, zero row outside the image) against the
@@ -937,6 +944,17 @@ def test_window_igemm_matches_gather_igemm(case):
         tol = (2e-4 if name == "colstats" else 2.0 ** -7) * scale
         assert err <= tol, f"{name}: window kernel differs by {err} (scale {scale})"
         assert (a - b).abs().mean().item() <= 1e-3 * scale, name
+    # ... and directly against torch's fp32 conv3d on the same 16-bit-rounded operands (the comparison
+    # above alone would pass if both kernels shared a defect)
+    xf = from_cl(x, B, (T, Hh, W), Ci).requires_grad_()
+    wr = rb(w.cpu()).requires_grad_()
+    yr = F.conv3d(xf, wr, stride=s, padding=p)
+    dyf = from_cl(dy, B, (T, Hh, W), Co)
+    yr.backward(dyf)
+    for idx, tag in ((1, "256-row tiles"), (2, "tall")):
+        close(from_cl(outs[idx][0], B, (T, Hh, W), Co), yr.detach(), name=f"window fwd vs torch ({tag})")
+        close(from_cl(outs[idx][2], B, (T, Hh, W), Ci), xf.grad, name=f"window dgrad vs torch ({tag})")
+        close(from_cl(outs[idx][3], B, (T, Hh, W), Ci), xf.grad + from_cl(res, B, (T, Hh, W), Ci), name=f"window dgrad + residual vs torch ({tag})")
 
 
 @pytest.mark.parametrize("case", [
@@ -1138,12 +1156,13 @@ def test_recall_metrics_on_device(golden_dir):
 
 
 @pytest.mark.parametrize("B,T,p", [(3, 114, 0.0), (2, 49, 0.1), (2, 128, 0.1), (1, 7, 0.0),
-                                   (2, 229, 0.0), (2, 229, 0.1), (1, 256, 0.1), (1, 129, 0.0), (2, 200, 0.0)])
+                                   (2, 229, 0.0), (2, 229, 0.1), (1, 256, 0.1), (1, 129, 0.0), (2, 200, 0.0),
+                                   (2, 316, 0.0), (1, 316, 0.1), (1, 257, 0.0), (1, 320, 0.1)])
 def test_fused_attention_matches_unfused_and_torch(B, T, p):
     """pp_attention_fwd / _bwd (scores in MFMA accumulators, probabilities recomputed in the backward from the forward's
-    log-sum-exp rows; T <= 128: one workgroup per clip and head, T <= 256 -- the 229 frames of BASELINE configs[4] --
-    64-query-row workgroups forward and 2 x 2 blocks of 128 backward) against the unfused HIP path (same dropout stream)
-    and, without dropout, against fp32 torch."""
+    log-sum-exp rows; T <= 128: one workgroup per clip and head, T <= 320 -- the 229 frames of BASELINE configs[4], the 316
+    frames of the reference's own 2.3-s clips at 44.1 kHz -- 64-query-row workgroups forward and 2 x 2 / 3 x 3 blocks of 128
+    backward) against the unfused HIP path (same dropout stream) and, without dropout, against fp32 torch."""
     from peppa_amd import audio as A
     g = torch.Generator().manual_seed(B * 100 + T)
     M, Tp = B * T, L.cpad(T)
@@ -1176,6 +1195,28 @@ def test_fused_attention_matches_unfused_and_torch(B, T, p):
 
 def rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("T", [321, 600, 1000])
+def test_unfused_attention_beyond_the_fused_kernels_reach(T):
+    """Clips longer than the fused kernels' 320 frames take batched GEMMs + pp_softmax_* (T <= 1024) on their own: against
+    fp32 torch.  (Round 3 refused T > 256 outright -- the reference's own clips have 316 frames.)"""
+    from peppa_amd import audio as A
+    B = 1
+    g = torch.Generator().manual_seed(T)
+    M, Tp = B * T, L.cpad(T)
+    qkv = (0.5 * torch.randn(M, 2304, generator=g)).to(torch.bfloat16).to(DEV)
+    dctx = torch.randn(M, 768, generator=g).to(torch.bfloat16).to(DEV)
+    ctx, P = A._attention_fwd(qkv, B, T, Tp, 0.125, True, (0.0, 0))
+    assert P.dtype != torch.float32          # the saved probabilities: the unfused path
+    dqkv = A._attention_bwd(dctx, qkv, ctx, P, B, T, Tp, 0.125, (0.0, 0))
+    torch.cuda.synchronize()
+    x = qkv.float().cpu().view(B, T, 3, 12, 64).requires_grad_()
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    ctx_ref = (torch.softmax(0.125 * q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(M, 768)
+    ctx_ref.backward(dctx.float().cpu())
+    close(ctx.float().cpu(), ctx_ref, name="unfused ctx vs torch")
+    close(dqkv.float().cpu(), x.grad.reshape(M, 2304), name="unfused dqkv vs torch")
 
 
 def test_gelu_bwd_with_fused_dropout_matches_two_passes():

@@ -106,13 +106,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const h16raw* __restrict__ 
         }
       }
     }
-    if (DBG) {
+    if (DBG == 1) {
       uint32_t kx = 0, kd = 0;
 #pragma unroll
       for (int c = 0; c < LN_MAXC; ++c)
         if (lane + 64 * c < nch) { kx ^= cx[c].x ^ cx[c].y ^ cx[c].z ^ cx[c].w; kd ^= cd[c].x ^ cd[c].y ^ cd[c].z ^ cd[c].w; }
       *(float4*)(dbg + ((long long)row * 64 + lane) * 4) = make_float4(s1, s2, __uint_as_float(kx), __uint_as_float(kd));
     }
+    const float part1 = s1, part2 = s2;      // (DBG == 2: this lane's partial sums, stored AFTER the row's dx)
     s1 = wave_sum(s1) / D;
     s2 = wave_sum(s2) / D;
 #pragma unroll
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const h16raw* __restrict__ 
         *(uint4*)(dx + (long long)row * D + ch * 8) = pack8(o);
       }
     }
+    if (DBG == 2) *(float4*)(dbg + ((long long)row * 64 + lane) * 4) = make_float4(part1, part2, s1, s2);
   }
   __shared__ float red[2][4][64 * 8 * LN_MAXC];
   const int w = threadIdx.x >> 6;
@@ -233,12 +235,14 @@ int main(int argc, char** argv) {
   } else printf("(no %s: aggressor 1 skipped)\n", libpath);
   hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
   auto victim = [&](int dbgmode, h16raw* out, float* d) {
-    if (dbgmode) hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nblk), dim3(256), 0, s1, dy, x, gam, mean, rstd, out, rows, D, rpw, ws, d);
+    if (dbgmode == 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nblk), dim3(256), 0, s1, dy, x, gam, mean, rstd, out, rows, D, rpw, ws, d);
+    else if (dbgmode == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nblk), dim3(256), 0, s1, dy, x, gam, mean, rstd, out, rows, D, rpw, ws, d);
     else hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(nblk), dim3(256), 0, s1, dy, x, gam, mean, rstd, out, rows, D, rpw, ws, d);
   };
   std::vector<uint4> hsave((size_t)MAXS * n16), hdbg((size_t)MAXS * ndbg16), hdbg_ref(ndbg16), href(n16);
   const char* names[] = {"none", "library dense wgrad (register-staged MFMA)", "MFMA loop, registers only", "MFMA loop + streaming loads", "streaming loads, no MFMA"};
-  for (int dbgmode = 0; dbgmode < 2; ++dbgmode) {
+  const char* vnames[] = {"as shipped            ", "debug stores mid-row  ", "debug stores after row"};
+  for (int dbgmode = 0; dbgmode < 3; ++dbgmode) {
     victim(dbgmode, ref, dbg_ref); CK(hipDeviceSynchronize());
     CK(hipMemcpy(href.data(), ref, (size_t)n16 * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(hdbg_ref.data(), dbg_ref, (size_t)ndbg16 * 16, hipMemcpyDeviceToHost));
     for (int ag = 0; ag < 5; ++ag) {
@@ -256,7 +260,7 @@ int main(int argc, char** argv) {
       }
       CK(hipDeviceSynchronize());
       int h[2]; CK(hipMemcpy(h, cnt, 8, hipMemcpyDeviceToHost));
-      printf("victim %s | aggressor %-44s: %d of %d launches differ\n", dbgmode ? "with debug stores" : "as shipped       ", names[ag], h[0], h[1]); fflush(stdout);
+      printf("victim %s | aggressor %-44s: %d of %d launches differ\n", vnames[dbgmode], names[ag], h[0], h[1]); fflush(stdout);
       if (!h[0]) continue;
       const int ns = h[0] < MAXS ? h[0] : MAXS;
       CK(hipMemcpy(hsave.data(), save_dx, (size_t)ns * n16 * 16, hipMemcpyDeviceToHost));
@@ -266,10 +270,26 @@ int main(int argc, char** argv) {
         for (int r = 0; r < rows; ++r) {
           int nd = 0; for (int c = 0; c < D; ++c) nd += got[r * D + c] != want[r * D + c];
           if (!nd) continue;
+          if (!dbgmode && s > 0) continue;
           printf("  failure %d: row %d (row %d of its wave), %d columns differ\n", s, r, r % rpw, nd);
           if (!dbgmode) continue;
           const uint4* dg = hdbg.data() + (size_t)s * ndbg16 + r * 64; const uint4* dr = hdbg_ref.data() + r * 64;
           int nl = 0;
+          if (dbgmode == 2) {     // partial sums (x, y) and the reduced, divided sums (z, w) of every lane
+            int npart = 0, ntot = 0;
+            for (int l = 0; l < 64; ++l) { npart += dg[l].x != dr[l].x || dg[l].y != dr[l].y; ntot += dg[l].z != dr[l].z || dg[l].w != dr[l].w; }
+            float a[4], b[4]; memcpy(a, &dg[0], 16); memcpy(b, &dr[0], 16);
+            printf("    lanes whose PARTIAL sums differ from the clean run: %d; lanes whose REDUCED sums differ: %d; lane 0: s1 %.9g (ref %.9g) s2 %.9g (ref %.9g)\n",
+                   npart, ntot, a[2], b[2], a[3], b[3]);
+            if (s > 1 || nd < 0) continue;
+            for (int l = 0; l < 64 && nl < 6; ++l)
+              if (dg[l].x != dr[l].x || dg[l].y != dr[l].y) {
+                memcpy(a, &dg[l], 16); memcpy(b, &dr[l], 16);
+                printf("      lane %2d: partial s1 %.9g (ref %.9g) [%08x %08x]  partial s2 %.9g (ref %.9g) [%08x %08x]\n", l, a[0], b[0], dg[l].x, dr[l].x, a[1], b[1], dg[l].y, dr[l].y);
+                ++nl;
+              }
+            continue;
+          }
           for (int l = 0; l < 64; ++l)
             if (memcmp(&dg[l], &dr[l], 16)) {
               float a[4], b[4]; memcpy(a, &dg[l], 16); memcpy(b, &dr[l], 16);
