@@ -65,20 +65,26 @@ def dense_case(name, M, N, K):
     print(f"{name:28s} M={M:8d} " + " | ".join(res), flush=True)
 
 
-T, S = 16, 56
-conv_case("stem2 45->64 (3,1,1)", 45, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (T, S, S))
-conv_case("l1 spatial 64->144", 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), (T, S, S))
-conv_case("l1 temporal 144->64", 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (T, S, S))
-conv_case("l2.0 spatial 64->230 s2", 64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), (T, S, S))
-conv_case("l2.0 temporal 230->128 s2", 230, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), (T, 28, 28))
-conv_case("l2 spatial 128->288", 128, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 28, 28))
-conv_case("l2 temporal 288->128", 288, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (8, 28, 28))
-conv_case("l3 spatial 256->576", 256, 576, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 14, 14))
-conv_case("l3 temporal 576->256", 576, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 14, 14))
-conv_case("l4 spatial 512->1152", 512, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 7, 7))
-conv_case("l4 temporal 1152->512", 1152, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 7, 7))
+# layer-1 geometry: GEOM="T,H,W" (default 16,56,56 = BASELINE configs[1]; the reference's own clips: GEOM=23,50,90 B=8)
+T, S1, S2 = (int(v) for v in os.environ.get("GEOM", "16,56,56").split(","))
+half = lambda v: (v + 1) // 2
+g1 = (T, S1, S2)
+g2 = (half(T), half(S1), half(S2))
+g3 = tuple(half(v) for v in g2)
+g4 = tuple(half(v) for v in g3)
+conv_case("stem2 45->64 (3,1,1)", 45, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), g1)
+conv_case("l1 spatial 64->144", 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), g1)
+conv_case("l1 temporal 144->64", 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), g1)
+conv_case("l2.0 spatial 64->230 s2", 64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), g1)
+conv_case("l2.0 temporal 230->128 s2", 230, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), (T, g2[1], g2[2]))
+conv_case("l2 spatial 128->288", 128, 288, (1, 3, 3), (1, 1, 1), (0, 1, 1), g2)
+conv_case("l2 temporal 288->128", 288, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), g2)
+conv_case("l3 spatial 256->576", 256, 576, (1, 3, 3), (1, 1, 1), (0, 1, 1), g3)
+conv_case("l3 temporal 576->256", 576, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), g3)
+conv_case("l4 spatial 512->1152", 512, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1), g4)
+conv_case("l4 temporal 1152->512", 1152, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), g4)
 conv_case("audio conv1 k3s2 T=7359", 512, 512, (3, 1, 1), (2, 1, 1), (0, 0, 0), (7359, 1, 1))
-M = B * 114
+M = B * int(os.environ.get("AUDIO_T", "114"))
 dense_case("qkv 768->2304", M, 2304, 768)
 dense_case("out 768->768", M, 768, 768)
 dense_case("ffn1 768->3072", M, 3072, 768)

@@ -48,7 +48,7 @@ def main(fetch_dir, write_dir, log, out_md, out_json):
     rows.sort(reverse=True)
     table = {}
     with open(out_md, "w") as f:
-        f.write("# Round 3: HBM bytes per matrix-core launch by shape (PMC)\n\n"
+        f.write("# HBM bytes per matrix-core launch by shape (PMC)\n\n"
                 f"`rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` over `tools/step_loop.py --isolated` "
                 f"({meta['steps']} steps, batch {meta['batch']}), joined with the launch log (tools/prof_traffic.py).  read = FETCH_SIZE KiB x 2 "
                 "(the gfx950 correction), written = WRITE_SIZE KiB.  algorithmic = operand rows once + weights + output (no halo, no "

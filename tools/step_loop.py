@@ -21,6 +21,7 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--samples", type=int, default=36800)
+ap.add_argument("--size", default="112", help="frame size H or HxW")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--isolated", action="store_true")
 ap.add_argument("--no-overlap-audio", action="store_true")
@@ -52,7 +53,8 @@ scaler = None
 if args.dtype == "fp16":
     from peppa_amd.amp import GradScaler
     scaler = GradScaler()
-b = synthetic_batch(args.batch, args.frames, 112, args.samples).to("cuda")
+hw = [int(v) for v in args.size.lower().split("x")]
+b = synthetic_batch(args.batch, args.frames, hw[0] if len(hw) == 1 else (hw[0], hw[1]), args.samples).to("cuda")
 
 
 def step(i):
