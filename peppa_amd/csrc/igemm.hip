@@ -35,6 +35,8 @@ int pp_opt_persist_cus = 256;   // workgroups of the persistent (one per CU) rin
 int pp_opt_ring_wn = 0;  // dense ring tile width in 16-column units (6, 8, 9; 0 = chosen per problem)
 int pp_opt_xcd_remap_wgrad = 1;
 int pp_opt_wgrad_flat = 1;
+int pp_opt_win_s2d = 1;
+int pp_opt_wgrad_group_ring = 0;
 // BatchNorm streaming passes (tools/bench_bn.py, layer-1 shapes): non-temporal STORES + 32 k workgroups instead of plain
 // stores + 4 k: apply 417 -> 370 us, backward apply 576 -> 485 us at 144 channels (4.4 / 4.8 -> 5.0 / 5.7 TB/s); non-temporal
 // loads on top bought nothing.  bit 0: non-temporal loads, bit 1: non-temporal stores.
@@ -69,6 +71,8 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "persistent_igemm")) { pp_opt_persistent = value; return PP_OK; }
   if (!strcmp(name, "xcd_remap_wgrad")) { pp_opt_xcd_remap_wgrad = value; return PP_OK; }
   if (!strcmp(name, "wgrad_flat")) { pp_opt_wgrad_flat = value; return PP_OK; }
+  if (!strcmp(name, "win_s2d")) { pp_opt_win_s2d = value; return PP_OK; }
+  if (!strcmp(name, "wgrad_group_ring")) { pp_opt_wgrad_group_ring = value; return PP_OK; }
   if (!strcmp(name, "bn_nt")) { pp_opt_bn_nt = value; return PP_OK; }
   if (!strcmp(name, "win_out_nt")) { pp_opt_win_out_nt = value; return PP_OK; }
   if (!strcmp(name, "bn_grid")) { pp_opt_bn_grid = value > 0 ? value : 32768; return PP_OK; }

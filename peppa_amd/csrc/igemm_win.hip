@@ -24,6 +24,7 @@ extern int pp_opt_persist_cus;
 extern int pp_opt_win_igemm;
 extern int pp_opt_win_stagger;
 extern int pp_opt_win_producers;
+extern int pp_opt_win_s2d;
 
 // Timing ablations for tools/probe/win_ablate.py (results are WRONG with any bit set; the shipped library has 0):
 // 1 weights only for a workgroup's first tile, 2 windows likewise, 4 no fragment reads / MFMAs, 8 no epilogue,
@@ -153,6 +154,8 @@ struct WinGeom {
   FastDiv dBlk;  // position blocks per clip (H*W / PB)
   int nblk, T, HW, PB, pshift;
   FastDiv dNb;   // column blocks per row block (tile -> (row block, column block))
+  int oH, oW;    // S2D: the (H, W) of dx; W, H above are then those of dy
+  int Mout;      // S2D: rows of dx
 };
 
 struct WinArgs {
@@ -190,10 +193,17 @@ struct WinArgs {
 // output as its dz: the tile is in registers / LDS anyway, so bn_bwd_reduce's pass over dz (2 B per element of HBM
 // traffic, a launch) disappears; its read of y moves here.
 // STG = staggered halves (spatial form, three weight slots): see the K-step below.
+// S2D = the data gradient of a (1,3,3) convolution with stride (1,2,2) as ONE launch that reads dy once.  A tile is 256 rows
+// of dy; for dx position (2 i + p, 2 j + q) only the taps of parity class (p, q) contribute, each reading dy at (i + di, j + dj)
+// with di, dj in {0, 1}: the window keeps the tile's rows plus W' + 1 rows AFTER it (none before), a K-step is one tap of one
+// 64-channel chunk and accumulates into its class's column tiles (4 classes x WN tiles per row tile), and the epilogue
+// scatters four output rows per dy row.  The per-class launches of the gather kernel this replaces each streamed dy again
+// (3.5x the traffic, 0.07-0.14 of the matrix peak: profiles/r03_shapes.md).  dy's channel count need not be a multiple of
+// 64: the last chunk's surplus channels read the neighbouring bytes and meet zero weights (absent DMA lanes).
 // PROD = four producer waves (8, 9: weights; 10, 11: windows) issue every LDS-DMA and do nothing else; the eight
 // multiplying waves issue none and never wait on vmcnt (wgrad_tw.hip measured why: a wave that multiplies is not at its
 // DMA instructions when the memory pipeline has room for them).  Twelve waves = three per SIMD = 168 registers each.
-template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false, bool STG = false, bool PROD = false, int HL = HALO>
+template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false, bool STG = false, bool PROD = false, int HL = HALO, bool S2D = false>
 __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap, const int out_nt) {
   constexpr int BM = 16 * MT * NW;
@@ -211,9 +221,12 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   // temporal tiles with narrow outputs: no halo rows at all and THREE window buffers -- the window of the phase after
   // next is in flight too, because a phase (3 short K-steps) is far shorter than an HBM round trip
   constexpr int HALO_ = (TW && WN <= 4) ? 0 : HL;
+  constexpr int HB = S2D ? 0 : HALO_, HA = HALO_;          // window rows before / after the tile's own
+  constexpr int NCLS = S2D ? 4 : 1;                        // output parity classes (column-tile groups of the accumulators)
+  static_assert(!S2D || (!TW && CC == 64 && !BNR && !BNA && !STG && MT == 2), "S2D: spatial form, 64-channel chunks");
   constexpr int NWIN = (TW && WN <= 4) ? 3 : 2;
   constexpr int D = NWIN - 1;                                 // phases of window look-ahead
-  constexpr int WROWS = BM + 2 * HALO_;
+  constexpr int WROWS = BM + HB + HA;
   constexpr int BN = 16 * WN;
   constexpr int B_BYTES = BN * 128;
   constexpr int XS = CC == 64 ? 128 : CC * 2 + 16;            // window row stride; 128-byte rows are XOR-swizzled
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   };
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
   const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bt, (short)0, (int)p.b_bytes, 0x00020000);
-  const int nchunk = g.cg / CC;
+  const int nchunk = S2D ? (g.cg + CC - 1) / CC : g.cg / CC;
 
   if (tid < 64) ((unsigned*)zrow)[tid] = 0u;
   float* const bna_tab = (float*)(zrow + 256 + 64);          // [scale BNA_CH][shift BNA_CH]
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
       row = o / XS;
       cb = o - row * XS;
     }
-    const int lr = row - HALO_;
+    const int lr = row - HB;
     const int rel = TW ? (lr >> g.pshift) * g.HW + (lr & (g.PB - 1)) : lr;
     w_voff[k] = (unsigned)(rel * g.cstride * 2 + cb);
   }
@@ -367,7 +380,8 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   }
   auto dma_weights = [&](unsigned char* slot, const int chunk_, const int j) __attribute__((always_inline)) {
     if ((ABL & 1) && !abl_first) return;
-    const unsigned koff = (CC == 64 ? (j < NTAP ? (unsigned)(j * g.cg) * 2u + kvoff[0] : ABSENT_K) : kvoff[j]) + (unsigned)(chunk_ * CC) * 2u;
+    const bool k_absent = S2D && chunk_ * CC + kqB * 8 >= g.cg;       // (S2D: the last chunk may be partial)
+    const unsigned koff = (CC == 64 ? ((j < NTAP && !k_absent) ? (unsigned)(j * g.cg) * 2u + kvoff[0] : ABSENT_K) : kvoff[j]) + (unsigned)(chunk_ * CC) * 2u;
     unsigned char* dst = slot + (8 * rwave) * 128;
 #pragma unroll
     for (int i = 0; i < NBI; ++i)
@@ -401,6 +415,12 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
       const int w = m - (int)q1 * g.W;
       const int h = (int)q1 - (int)fdiv(q1, g.dH_) * g.H;
       unsigned v = 0;
+      if (S2D) {      // tap (dh, dw) reads dy at (h + (dh == 0), w + (dw == 0))
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v |= (unsigned)((h + (t / 3 == 0 ? 1 : 0) < g.H) & (w + (t % 3 == 0 ? 1 : 0) < g.W)) << t;
+        vmask[mt] = m < g.M ? v : 0u;
+        continue;
+      }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int sh = g.sign * (t / 3 - 1), sw = g.sign * (t % 3 - 1);
@@ -410,16 +430,17 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     }
   };
 
-  f32x4 acc[MT][WN];
+  f32x4 acc[MT][NCLS * WN];
   // ---- fragment addressing, prepared once per workgroup.  Window row of fragment row (mt, fr) = rowA[mt] + tap offset;
   // 64-channel chunks: a K-step is one tap (scalar offset), rows are XOR-swizzled; 48-channel chunks: the lane's k-octet
   // of K-step j, half ks has its own (tap, channel) -- byte offset and tap bit per (j, ks) ----------------------------
   int lutv[NTAP];
 #pragma unroll
-  for (int t = 0; t < NTAP; ++t) lutv[t] = TW ? g.sign * (t - 1) * g.PB : g.sign * ((t / 3 - 1) * g.W + (t % 3 - 1));
+  for (int t = 0; t < NTAP; ++t)
+    lutv[t] = TW ? g.sign * (t - 1) * g.PB : S2D ? (t / 3 == 0 ? g.W : 0) + (t % 3 == 0 ? 1 : 0) : g.sign * ((t / 3 - 1) * g.W + (t % 3 - 1));
   int rowA[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) rowA[mt] = wave * (16 * MT) + mt * 16 + fr + HALO_;
+  for (int mt = 0; mt < MT; ++mt) rowA[mt] = wave * (16 * MT) + mt * 16 + fr + HB;
   unsigned aoff[CC == 64 ? 1 : NKC][2], abit[CC == 64 ? 1 : NKC][2];
   if (CC != 64) {
 #pragma unroll
@@ -527,14 +548,16 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
       issue_dmas(3);
       return;
     }
+    // S2D: tap j = (dh, dw) belongs to output parity class ((dh + 1) & 1, (dw + 1) & 1) -- its own column tiles
+    const int c0 = S2D ? ((((j / 3) + 1) & 1) * 2 + (((j % 3) + 1) & 1)) * WN : 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int jn = 0; jn < WN; ++jn) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt][jn] = TRC ? PP_MFMA16(bfm[REUSE_B ? 0 : ks][jn], af[ks][mt], acc[mt][jn], 0, 0, 0)
-                            : PP_MFMA16(af[ks][mt], bfm[REUSE_B ? 0 : ks][jn], acc[mt][jn], 0, 0, 0);
+          acc[mt][c0 + jn] = TRC ? PP_MFMA16(bfm[REUSE_B ? 0 : ks][jn], af[ks][mt], acc[mt][c0 + jn], 0, 0, 0)
+                                 : PP_MFMA16(af[ks][mt], bfm[REUSE_B ? 0 : ks][jn], acc[mt][c0 + jn], 0, 0, 0);
         if (REUSE_B && ks == 0) {          // (pinned: left alone, hipcc sinks these reads to just before their MFMAs)
           bfm[0][jn] = load_b(1, jn);
           __builtin_amdgcn_sched_barrier(0);
@@ -546,8 +569,19 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 
   // ---- epilogue (plain bf16 store, optional residual add, optional BatchNorm column statistics); igemm.hip's ------
   const int ncols_store = (p.N + 7) & ~7;
-  auto epilogue = [&](const int mb_e, const int nb_e, unsigned char* const ebuf, unsigned char* const sbuf) __attribute__((always_inline)) {
+  // S2D: dy row m (tile space) and parity class cls -> dx row, or -1 where that position does not exist
+  auto s2d_row = [&](const int m, const int cls) __attribute__((always_inline)) -> int {
+    const uint32_t q1 = fdiv((uint32_t)m, g.dW_);
+    const int j = m - (int)q1 * g.W;
+    const uint32_t nt = fdiv(q1, g.dH_);
+    const int i = (int)q1 - (int)nt * g.H;
+    const int u = 2 * i + (cls >> 1), v = 2 * j + (cls & 1);
+    return (m < g.M && u < g.oH && v < g.oW) ? ((int)nt * g.oH + u) * g.oW + v : -1;
+  };
+  auto epilogue = [&](const int mb_e, const int nb_e, unsigned char* const ebuf, unsigned char* const sbuf, const int cls) __attribute__((always_inline)) {
     const int m_wave = mb_e * BM + wave * (16 * MT);
+    const int ca = cls * WN;                          // this class's column tiles of the accumulators (S2D; else 0)
+    const int m_lim = S2D ? g.Mout : g.M;
     unsigned char* stg = ebuf + wave * 16 * STG_STRIDE;
     unsigned char* stg_w = stg + (fq * 4) * STG_STRIDE + fr * 2;
     // BNR: a lane keeps ONE 8-column chunk for the whole tile (RPI rows in flight per wave pass), so that its sixteen
@@ -574,9 +608,10 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         const int row = BNR ? b_rsub + RPI * it : cid / CPR;
         const int ch = BNR ? b_ch : cid % CPR;
         const bool live = BNR ? (b_rsub < RPI && row < 16) : cid < 32 * WN;
-        const int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
+        int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
+        if (S2D) { m = s2d_row(m, cls); if (m < 0) m = m_lim; }
         const int col = nb_e * BN + ch * 8;
-        rpre[mt * NIT + it] = (live && m < g.M && col < ncols_store) ? *(const uint4*)(p.residual + (long long)m * p.ldr + col) : make_uint4(0, 0, 0, 0);
+        rpre[mt * NIT + it] = (live && m < m_lim && col < ncols_store) ? *(const uint4*)(p.residual + (long long)m * p.ldr + col) : make_uint4(0, 0, 0, 0);
       }
     };
     if (RES) {
@@ -610,11 +645,11 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         if (TRC) {        // four consecutive columns of row fr: one 8-byte write (acc[mt][j][r] = C[row fr][j * 16 + 4 fq + r])
-          const u32x2 w = {pack2(acc[mt][j][0], acc[mt][j][1]), pack2(acc[mt][j][2], acc[mt][j][3])};
+          const u32x2 w = {pack2(acc[mt][ca + j][0], acc[mt][ca + j][1]), pack2(acc[mt][ca + j][2], acc[mt][ca + j][3])};
           *(u32x2*)(stg + fr * STG_STRIDE + j * 32 + fq * 8) = w;
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) *(h16raw*)(stg_w + r * STG_STRIDE + j * 32) = f2h(acc[mt][j][r]);
+          for (int r = 0; r < 4; ++r) *(h16raw*)(stg_w + r * STG_STRIDE + j * 32) = f2h(acc[mt][ca + j][r]);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -640,9 +675,10 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         const int row = BNR ? b_rsub + RPI * it : cid / CPR;
         const int ch = BNR ? b_ch : cid % CPR;
         const bool live = BNR ? (b_rsub < RPI && row < 16) : cid < 32 * WN;
-        const int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
+        int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
+        if (S2D) { m = s2d_row(m, cls); if (m < 0) m = m_lim; }
         const int col = nb_e * BN + ch * 8;
-        if (live && m < g.M && col < ncols_store) {
+        if (live && m < m_lim && col < ncols_store) {
           const u32x4 vv = vvs[it];
           uint4 v = make_uint4(vv[0], vv[1], vv[2], vv[3]);
           if (RES) {
@@ -726,7 +762,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         }
       }
     }
-    if (MT == 2 && p.colstats) {   // per-column sum / sum of squares per 128 output rows, deterministic (igemm.hip)
+    if (MT == 2 && !S2D && p.colstats) {   // per-column sum / sum of squares per 128 output rows, deterministic (igemm.hip)
       float* statbuf = (float*)sbuf;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
@@ -863,7 +899,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NCLS * WN; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const int next_tile = tile_index(it + 1);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -996,8 +1032,11 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     }
     PP_STAMP(4)
     if constexpr (COMP) {
-      if (!(ABL & 8)) epilogue(mb_done, nb_done, ebuf, sbuf);
-    } else if (MT == 2 && p.colstats) {
+      if (!(ABL & 8)) {
+#pragma unroll
+        for (int cls = 0; cls < NCLS; ++cls) epilogue(mb_done, nb_done, ebuf, sbuf, cls);
+      }
+    } else if (MT == 2 && !S2D && p.colstats) {
       __builtin_amdgcn_s_barrier();     // (the statistics' barrier inside the epilogue)
     }
     PP_STAMP(5)
@@ -1025,12 +1064,14 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 template <int WN, int CC, int MT, bool TW>
 constexpr bool bnr_built() { return TW ? (CC == 64 && WN == 4) : (WN == 4 || WN == 8); }   // (MT x NIT <= 8 chunks of y per lane)
 
-template <int WN, int CC, int MT, int NBS, bool TW = false, int HL = HALO>
+template <int WN, int CC, int MT, int NBS, bool TW = false, int HL = HALO, bool S2D = false>
 int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   constexpr int BN = 16 * WN, BM = 16 * MT * NW;
   const pp_gather& gg = d.g;
   WinGeom g;
   g.W = gg.Gw; g.H = gg.Gh; g.M = d.M; g.cstride = gg.cstride; g.cg = gg.cg;
+  g.oH = gg.Rh; g.oW = gg.Rw; g.Mout = d.M;
+  if (S2D) g.M = (int)((long long)d.M / ((long long)gg.Rt * gg.Rh * gg.Rw) * gg.Gt * gg.Gh * gg.Gw);   // tiles walk the rows of dy
   g.sign = gg.mode == PP_CONV_FWD ? 1 : -1;
   g.dW_ = make_fastdiv((uint32_t)gg.Gw);
   g.dH_ = make_fastdiv((uint32_t)gg.Gh);
@@ -1050,16 +1091,22 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   a.bnr_relu = d.bnr_relu; a.bnr_partials = d.bnr_partials;
   const bool bna = d.a_bn_scale != nullptr;
   a.bna_scale = d.a_bn_scale; a.bna_shift = d.a_bn_shift; a.bna_relu = d.a_bn_relu;
-  a.a_bytes = (unsigned)((((long long)d.M - 1) * gg.cstride + gg.cg) * 2);
+  a.a_bytes = (unsigned)((((long long)g.M - 1) * gg.cstride + gg.cg) * 2);
   const long long b_bytes = (((long long)d.b_rows - 1) * d.ldb + d.K) * 2;
   if (b_bytes <= 0 || b_bytes >= 0x40000000LL) { pp_set_error("pp_igemm: weight matrix too large for the window kernel"); return PP_ERR_INVALID; }
   a.b_bytes = (unsigned)b_bytes;
-  const long long nblk_m = ((long long)d.M + BM - 1) / BM;
+  const long long nblk_m = ((long long)g.M + BM - 1) / BM;
   const long long ntiles = nblk_m * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
   dim3 grid((unsigned)gx, 1, 1), block(NT);
-  if constexpr (!TW && HL != HALO) {
+  if constexpr (S2D) {
+    if (bna) { pp_set_error("pp_igemm: fused BatchNorm apply is built for the temporal window kernel only"); return PP_ERR_INVALID; }
+    if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, false, HL, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+    else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, false, HL, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+    PP_LAUNCH_CHECK();
+    return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
+  } else if constexpr (!TW && HL != HALO) {
     // frames wider than 63 (HL = 96 rows of halo): the producer form only -- no BatchNorm-backward sums in the epilogue
     // (the caller runs pp_bn_bwd_reduce: PP_BNR_SKIPPED), no staggered / lockstep variants
     if (bna) { pp_set_error("pp_igemm: fused BatchNorm apply is built for the temporal window kernel only"); return PP_ERR_INVALID; }
@@ -1176,6 +1223,13 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
     if (g.cg == 144 && n16 <= 4) return launch_win<4, 48, 2, 9, true>(d, s);
     return 1;
   }
+  // the data gradient of a (1,3,3) convolution with stride (1,2,2) (layers 2.0 / 3.0 / 4.0): one launch, dy read once
+  const bool s2d_ok = pp_opt_win_s2d && g.mode == PP_CONV_DGRAD && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre &&
+                      !d.omap && d.drop_p == 0.f && g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 2 && g.sw == 2 && g.pt == 0 &&
+                      g.ph == 1 && g.pw == 1 && g.Gt == g.Rt && g.Gh == (g.Rh + 1) / 2 && g.Gw == (g.Rw + 1) / 2 && g.Gw + 1 <= HALO &&
+                      d.K == 9 * g.cg && g.cg % 8 == 0 && g.cstride >= ((g.cg + 63) & ~63) - 56 &&
+                      (long long)d.M * 2 < 0x7f000000LL && (long long)d.M / 2 * g.cstride < 0x7f000000LL && (!d.residual || d.ldr % 8 == 0);
+  if (s2d_ok) return launch_win<4, 64, 2, 3, false, HALO, true>(d, s);
   constexpr int HALO_WIDE = 96;
   const bool shape_ok = conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre && !d.omap && d.drop_p == 0.f &&
                         g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 &&

@@ -13,6 +13,7 @@
 int pp_validate_gather(const pp_gather& g, int K, const char* who);
 extern int pp_opt_xcd_remap_wgrad;
 extern int pp_opt_wgrad_flat;
+extern int pp_opt_wgrad_group_ring;
 extern int pp_opt_ring_wgrad;
 extern int pp_opt_sw_wgrad;
 extern int pp_opt_deterministic;
@@ -413,7 +414,7 @@ __device__ __forceinline__ void wait_vmcnt_dyn(const int n) {   // n is wave-uni
 template <int WI, int NWV, int MODE, bool BIAS>
 __global__ __launch_bounds__(64 * NWV, 1) void wgrad_ring_kernel(const pp_wgrad_desc p, const WGeom wg, const int nblk_i,
                                                                    const int nblk_j, const int rows_per_split,
-                                                                   const int xcd_remap) {
+                                                                   const int xcd_remap, const int flat) {
   constexpr int NT = 64 * NWV;
   constexpr int TJR = 32 * NWV;                                   // columns of dW per workgroup
   constexpr int TI = 16 * WI;
@@ -435,12 +436,27 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad_ring_kernel(const pp_wgrad_
     const int xq = nwg >> 3, xr = nwg & 7, xcd = b0 & 7;
     bid = xcd_remap ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b0 >> 3) : b0;
   }
-  const int ib = bid % nblk_i; bid /= nblk_i;
-  const int jb = bid % nblk_j; bid /= nblk_j;
-  const int split = bid;
+  int ib, jb, split;
   const h16raw* X = (const h16raw*)p.X;
   const h16raw* dY = (const h16raw*)p.dY;
   float* __restrict__ dW = p.dW;
+  float* dbias_z = BIAS ? p.dbias : nullptr;
+  if (flat) {      // grouped launch (pointer table), no M split: (problem, tile) in slab-sharing order, see wgrad_kernel
+    const int tiles = nblk_i * nblk_j;
+    const int z = bid / tiles;
+    const int r = bid - z * tiles;
+    if (nblk_j <= nblk_i) { jb = r % nblk_j; ib = r / nblk_j; } else { ib = r % nblk_i; jb = r / nblk_i; }
+    split = 0;
+    const unsigned long long* e = p.ptr_table + 4 * z;
+    X = (const h16raw*)e[0];
+    dY = (const h16raw*)e[1];
+    dW = (float*)e[2];
+    dbias_z = BIAS ? (float*)e[3] : nullptr;
+  } else {
+    ib = bid % nblk_i; bid /= nblk_i;
+    jb = bid % nblk_j; bid /= nblk_j;
+    split = bid;
+  }
   const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)OOB, 0x00020000);
   const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, (short)0, (int)OOB, 0x00020000);
   const pp_gather& g = p.g;
@@ -636,7 +652,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad_ring_kernel(const pp_wgrad_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + a * 16 + fq * 4 + r;
-        if (i < p.Ni) atomicAdd(p.dbias + i, bacc[a][r]);
+        if (i < p.Ni) atomicAdd(dbias_z + i, bacc[a][r]);
       }
   }
   // fp32 tile through LDS so that every atomic wave-instruction adds 256 contiguous bytes
@@ -760,6 +776,8 @@ int launch_ring(const pp_wgrad_desc& d, hipStream_t s) {
     if (eff > best_eff + 1e-9) { best_eff = eff; best = ms; }
   }
   int msplit = d.msplit > 0 ? d.msplit : (int)best;
+  const int flat = d.ptr_table ? 1 : 0;          // grouped: every tile reduces its whole M (no sum crosses workgroups)
+  if (flat) msplit = 1;
   const long long sps = (steps + msplit - 1) / msplit;
   msplit = (int)((steps + sps - 1) / sps);
   const int rows_per_split = (int)(sps * MS);
@@ -767,12 +785,12 @@ int launch_ring(const pp_wgrad_desc& d, hipStream_t s) {
   wg.dRw = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rw));
   wg.dRh = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rh));
   wg.dRt = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rt));
-  dim3 grid((unsigned)(tiles * msplit), 1, 1), block(64 * NWV);
+  dim3 grid((unsigned)(tiles * msplit * (flat ? d.nbatch : 1)), 1, 1), block(64 * NWV);
   if (d.g.mode == PP_DENSE) {
-    if (d.dbias) hipLaunchKernelGGL((wgrad_ring_kernel<WI, NWV, PP_DENSE, true>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
-    else hipLaunchKernelGGL((wgrad_ring_kernel<WI, NWV, PP_DENSE, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+    if (d.dbias) hipLaunchKernelGGL((wgrad_ring_kernel<WI, NWV, PP_DENSE, true>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad, flat);
+    else hipLaunchKernelGGL((wgrad_ring_kernel<WI, NWV, PP_DENSE, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad, flat);
   } else {
-    hipLaunchKernelGGL((wgrad_ring_kernel<WI, NWV, PP_CONV_FWD, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad);
+    hipLaunchKernelGGL((wgrad_ring_kernel<WI, NWV, PP_CONV_FWD, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad, flat);
   }
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -831,6 +849,17 @@ static int wgrad_dispatch(const pp_wgrad_desc* dp, pp_stream_t stream, long long
     if (rc_tw != 1) return rc_tw;
   }
   const int n16 = (d.Ni + 15) / 16;
+  if (d.ptr_table && pp_opt_wgrad_group_ring && d.g.mode == PP_DENSE && n16 > 4 && d.M >= 1024) {
+    // grouped Linear weight gradients on the ring form: 128 / 144 x 192 / 256 tiles of dW (eight waves, one workgroup per CU)
+    // halve the number of tiles that re-read a dY / X slab against the 128 x 128 tiles of the register-staged kernel; every
+    // tile still reduces its whole M, so its single fp32 add per element lands on a zero: bitwise reproducible
+    if (ws_query) { *ws_query = 0; return PP_OK; }
+    const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
+    const int j6 = ((d.Kj + 191) / 192) * 192, j8 = ((d.Kj + 255) / 256) * 256;
+    const bool w9 = c9 <= c8, v6 = j6 < j8;
+    if (w9) return v6 ? launch_ring<9, 6>(d, s) : launch_ring<9, 8>(d, s);
+    return v6 ? launch_ring<8, 6>(d, s) : launch_ring<8, 8>(d, s);
+  }
   if (pp_opt_ring_wgrad && !pp_opt_deterministic && d.nbatch == 1 && !d.ptr_table && n16 > 4 && (long long)d.M >= pp_opt_ring_wgrad) {
     // ring tiles: 128 or 144 rows of dW (less padding wins) x 192 or 256 columns (ditto; 192 on ties)
     const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;

@@ -256,6 +256,17 @@ def _conv_dgrad_strided(dy, geom, wd, residual):
     return dx
 
 
+WIN_S2D = True    # stride-(1,2,2) spatial data gradients as ONE window-kernel launch that reads dy once (pp_set_option "win_s2d")
+
+
+def _s2d_window(geom):
+    """Does pp_igemm take this data gradient with the window kernel's S2D form (csrc/igemm_win.hip: a (1,3,3) convolution
+    with stride (1,2,2), pad (0,1,1), output at most 63 wide)?  Then conv_dgrad issues ONE launch over the whole gather
+    instead of one gather-kernel launch per output parity class."""
+    return (WIN_S2D and geom.k == (1, 3, 3) and geom.s == (1, 2, 2) and geom.p == (0, 1, 1) and geom.Wo + 1 <= 64 and
+            geom.Min >= H.WIN_IGEMM_DEFAULT and geom.Ho == (geom.Hi + 1) // 2 and geom.Wo == (geom.Wi + 1) // 2)
+
+
 MASKED_STRIDED_DGRAD = False   # A/B: stride-2 data gradients as ONE launch with masked taps instead of parity classes
 FUSE_BN_BWD_REDUCE = False   # consumer BatchNorm-backward sums in the data-gradient epilogue: built, tested, and OFF -- measured slower (see DESIGN.md)
 
@@ -266,7 +277,7 @@ def conv_dgrad(dy, geom, wd, *, residual=None, consumer=None):
     consumer = (y, z or None, BNSaved, relu) of the BatchNorm unit that receives dx as its dz: its backward sums
     (sum g, sum g * xhat) are then accumulated in the epilogue of the window kernels while the tile is on chip, and
     `consumer_partials(dx)` hands them to bn_bwd, which skips its own pass over dz."""
-    if geom.groups == 1 and max(geom.s) == 2 and not MASKED_STRIDED_DGRAD:
+    if geom.groups == 1 and max(geom.s) == 2 and not MASKED_STRIDED_DGRAD and not _s2d_window(geom):
         return _conv_dgrad_strided(dy, geom, wd, residual)
     dx = empty((geom.Min, geom.in_cstride), act16(), dy)
     if geom.groups == 1:

@@ -258,6 +258,33 @@ def test_grouped_linear_wgrad_matches_torch_and_is_bitwise_reproducible(M, N, K,
             assert torch.equal(dw, dw0) and torch.equal(db, db0), rep
 
 
+@pytest.mark.parametrize("flat,ring", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K,n", [(7296, 3072, 768, 3), (1100, 768, 3072, 5), (1030, 2304, 768, 2), (1500, 768, 768, 12)])
+def test_grouped_linear_wgrad_tile_orders_and_ring_form_agree(M, N, K, n, flat, ring):
+    """The grouped launch in its three forms -- round 3's order (one problem per grid.z slice), the flat slab-sharing order
+    (default), and the LDS-DMA ring kernel's 128 x 256 tiles (option wgrad_group_ring) -- against torch fp32; each form is
+    bitwise reproducible (every tile reduces its whole M)."""
+    g = torch.Generator().manual_seed(M + N + n)
+    items, refs = [], []
+    for i in range(n):
+        x = rb(torch.randn(M, K, generator=g))
+        dy = rb(torch.randn(M, N, generator=g))
+        items.append((x.to(torch.bfloat16).to(DEV), dy.to(torch.bfloat16).to(DEV)))
+        refs.append((dy.t() @ x, dy.sum(0)))
+    try:
+        H.set_option("wgrad_flat", flat)
+        H.set_option("wgrad_group_ring", ring)
+        outs = [[(dw.clone(), db.clone()) for dw, db in L.linear_wgrad_group(items, M, N, K)] for _ in range(2)]
+        torch.cuda.synchronize()
+    finally:
+        H.set_option("wgrad_flat", 1)
+        H.set_option("wgrad_group_ring", H.WGRAD_GROUP_RING_DEFAULT)
+    for (dw, db), (dw2, db2), (rw, rbias) in zip(outs[0], outs[1], refs):
+        close(dw, rw, name="grouped wgrad")
+        close(db, rbias, name="grouped bias grad")
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("N", [1, 4, 37, 64, 512])
 def test_hardest_negative_loss_opt_in(N):
     """Opt-in extension (BASELINE north_star: "in-batch hardest-negative mining with wavefront-64 argmin"; the REFERENCE has none,
@@ -740,6 +767,56 @@ def test_strided_dgrad_with_residual_accumulate():
     dx = L.conv_dgrad(to_cl(dy, geom.out_cstride), geom, wd, residual=to_cl(res, geom.in_cstride))
     torch.cuda.synchronize()
     close(from_cl(dx, B, (T, Hh, W), Ci), x.grad + res, name="strided dgrad + residual")
+
+
+@pytest.mark.parametrize("case", [
+    # Ci, Co, B, T, H, W -- (1,3,3) convolutions with stride (1,2,2): the first convolution of layers 2 / 3 / 4
+    (64, 230, 2, 3, 56, 56),      # layer 2.0 at the BASELINE geometry: dy has 240 channels (3.75 chunks of 64), one column block
+    (128, 460, 1, 2, 28, 28),     # layer 3.0: two column blocks, 464 channels (7.25 chunks)
+    (64, 230, 1, 2, 25, 45),      # odd height AND width (the reference's own 100 x 180 clips at layer 2.0): dx rows / columns without
+                                  # a partner in the last dy row / column
+    (256, 921, 1, 1, 13, 23),     # layer 4.0 at that geometry: four column blocks, 928 channels (14.5 chunks)
+    (64, 96, 2, 2, 9, 11),        # tiny: most of a tile's window lies in other frames
+    (64, 230, 1, 1, 40, 126),     # widest supported output (W' + 1 = 64)
+])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_strided_dgrad_window_kernel_matches_parity_classes_and_torch(case, with_res):
+    """S2D form of the window kernel (csrc/igemm_win.hip): the stride-(1,2,2) data gradient as ONE launch that reads dy once
+    and scatters four output parity classes, against the per-class gather launches it replaces and against torch."""
+    Ci, Co, B, T, Hh, W = case
+    k, s, p = (1, 3, 3), (1, 2, 2), (0, 1, 1)
+    g = torch.Generator().manual_seed(Ci + Co + Hh)
+    x = rb(torch.randn(B, Ci, T, Hh, W, generator=g)).requires_grad_()
+    w = rb(torch.randn(Co, Ci, *k, generator=g) / math.sqrt(9 * Ci))
+    y_ref = F.conv3d(x, w, stride=s, padding=p)
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    res = rb(torch.randn(B, Ci, T, Hh, W, generator=g))
+    geom = L.ConvGeom(B, (T, Hh, W), Ci, Co, k, s, p)
+    _, wd = L.prep_conv_weights(w.to(DEV), geom)
+    dyc = to_cl(dy, geom.out_cstride)
+    resc = to_cl(res, geom.in_cstride) if with_res else None
+    outs = []
+    try:
+        for s2d in (False, True):
+            L.WIN_S2D = s2d
+            prev_thr = H.WIN_IGEMM_DEFAULT
+            H.set_option("win_igemm", 1)          # (the tiny cases lie below the default row threshold)
+            H.WIN_IGEMM_DEFAULT = 1
+            try:
+                dx = L.conv_dgrad(dyc, geom, wd, residual=resc)
+                torch.cuda.synchronize()
+            finally:
+                H.WIN_IGEMM_DEFAULT = prev_thr
+                H.set_option("win_igemm", prev_thr)
+            outs.append(dx.float().cpu())
+    finally:
+        L.WIN_S2D = True
+    ref = x.grad + (res if with_res else 0)
+    close(from_cl(outs[1], B, (T, Hh, W), Ci), ref, name="S2D window dgrad vs torch")
+    scale = outs[0].abs().max().item()
+    assert (outs[0] - outs[1]).abs().max().item() <= 2.0 ** -7 * scale, "S2D differs from the parity-class launches"
+    assert (outs[1][:, Ci:] == 0).all()       # padded channels stay exact zeros
 
 
 @pytest.mark.parametrize("case", [

@@ -76,6 +76,14 @@ def set_switch(name, on):
     elif name in ("tw_producers", "tw_narrow", "ring_producers"):
         from peppa_amd import hip as H
         H.set_option(name, 1 if on else 0)
+    elif name == "win_tall":                  # 512-row window tiles for the narrow-output data gradient (1) against 256-row tiles (0)
+        from peppa_amd import hip as H
+        H.set_option("win_tall", 1 if on else 0)
+    elif name == "win_s2d":                   # stride-2 spatial data gradients as one window-kernel launch
+        L.WIN_S2D = on
+    elif name == "wgrad_flat":
+        from peppa_amd import hip as H
+        H.set_option("wgrad_flat", 1 if on else 0)
     elif name == "win_stagger":
         from peppa_amd import hip as H
         H.set_option("win_stagger", 1 if on else 0)
@@ -86,7 +94,7 @@ def set_switch(name, on):
         raise SystemExit(f"unknown switch {name}")
 
 
-defaults = {"win_producers_all": True, "ring_producers": True, "win_producers_tw": True, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
+defaults = {"win_tall": True, "win_s2d": True, "wgrad_flat": True, "win_producers_all": True, "ring_producers": True, "win_producers_tw": True, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
 for _ in range(3):
     step(0)
 for name in sys.argv[1:]:
