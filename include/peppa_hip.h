@@ -42,7 +42,12 @@ int pp_experimental_build(void);
  *   "sw_wgrad"     n   sliding-window weight gradients ((1,3,3) and (3,1,1) stride-1 convs) once M >= n (default 4096;
  *                      1 also takes shapes the (3,1,1) kernel would decline as not worth it)
  *   "ring_wgrad"   n   LDS-DMA ring variant of the generic weight gradient once M >= n (default 0 = never)
- *   "win_tall"     0/1/2  512-row window tiles for narrow outputs (1: with enough rows, the default; 2: always)
+ *   "win_tall"     0/1/2  512-row window tiles for narrow outputs (0: never, the default since round 4 -- the 256-row tile
+ *                      reads its operand once; 1: with enough rows; 2: always)
+ *   "win_s2d"      0/1 stride-(1,2,2) spatial data gradients as ONE window-kernel launch that reads dy once (default 1)
+ *   "win_partial"  0/1 window kernels also for channel counts that are no multiple of 48 / 64 (464, 928): 64-channel chunks,
+ *                      the last one partial (default 1)
+ *   "wgrad_group_ring" 0/1 grouped weight gradients on the ring kernel's 128 x 256 tiles (default 0: measured slower)
  *   "deterministic" 0/1  bitwise-reproducible results: every sum that crosses workgroups is taken in a fixed order instead
  *                      of by fp32 atomics -- weight gradients through per-split slabs (pp_wgrad_desc.ws) and an ordered
  *                      pass, the wav2vec2 conv0 statistics / weight-norm sums / column sums by one workgroup per sum,

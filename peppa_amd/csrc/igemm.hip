@@ -18,7 +18,10 @@
 
 int pp_opt_xcd_remap_igemm = 1;
 int pp_opt_persistent = 1;
-int pp_opt_win_tall = 1;       // window kernel: 512-row tiles (four row tiles per wave) for narrow outputs
+int pp_opt_win_tall = 0;       // window kernel: 512-row tiles (four row tiles per wave) for narrow outputs: 1 with enough rows, 2 always.
+                               // Default 0 since round 4: with the producer waves the 256-row tile is as fast alone (614 vs 618 us on the
+                               // layer-1 data gradient), reads 1.0x instead of 1.8x its operand (two 70-KB windows per CU no longer fit an
+                               // XCD's L2 between chunk passes) and the step is 0.1 ms faster with it (tools/ab_step.py win_tall)
 int pp_opt_deterministic = 0;   // ordered reductions instead of fp32 atomics wherever a sum crosses workgroups (slower; see the header)
 int pp_opt_tw_producers = 1;   // temporal sliding-window weight gradient: three extra waves issue the LDS-DMAs, the nine multiplying waves none
 int pp_opt_tw_narrow = 1;      // temporal sliding-window weight gradient: 48-channel blocks with a deep look-ahead for cg <= 48
@@ -36,6 +39,7 @@ int pp_opt_ring_wn = 0;  // dense ring tile width in 16-column units (6, 8, 9; 0
 int pp_opt_xcd_remap_wgrad = 1;
 int pp_opt_wgrad_flat = 1;
 int pp_opt_win_s2d = 1;
+int pp_opt_win_partial = 1;
 int pp_opt_wgrad_group_ring = 0;
 // BatchNorm streaming passes (tools/bench_bn.py, layer-1 shapes): non-temporal STORES + 32 k workgroups instead of plain
 // stores + 4 k: apply 417 -> 370 us, backward apply 576 -> 485 us at 144 channels (4.4 / 4.8 -> 5.0 / 5.7 TB/s); non-temporal
@@ -72,6 +76,7 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "xcd_remap_wgrad")) { pp_opt_xcd_remap_wgrad = value; return PP_OK; }
   if (!strcmp(name, "wgrad_flat")) { pp_opt_wgrad_flat = value; return PP_OK; }
   if (!strcmp(name, "win_s2d")) { pp_opt_win_s2d = value; return PP_OK; }
+  if (!strcmp(name, "win_partial")) { pp_opt_win_partial = value; return PP_OK; }
   if (!strcmp(name, "wgrad_group_ring")) { pp_opt_wgrad_group_ring = value; return PP_OK; }
   if (!strcmp(name, "bn_nt")) { pp_opt_bn_nt = value; return PP_OK; }
   if (!strcmp(name, "win_out_nt")) { pp_opt_win_out_nt = value; return PP_OK; }

@@ -25,6 +25,7 @@ extern int pp_opt_win_igemm;
 extern int pp_opt_win_stagger;
 extern int pp_opt_win_producers;
 extern int pp_opt_win_s2d;
+extern int pp_opt_win_partial;
 
 // Timing ablations for tools/probe/win_ablate.py (results are WRONG with any bit set; the shipped library has 0):
 // 1 weights only for a workgroup's first tile, 2 windows likewise, 4 no fragment reads / MFMAs, 8 no epilogue,
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   };
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
   const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bt, (short)0, (int)p.b_bytes, 0x00020000);
-  const int nchunk = S2D ? (g.cg + CC - 1) / CC : g.cg / CC;
+  const int nchunk = CC == 64 ? (g.cg + CC - 1) / CC : g.cg / CC;   // (64-channel chunks: the last one may be partial, see dma_weights)
 
   if (tid < 64) ((unsigned*)zrow)[tid] = 0u;
   float* const bna_tab = (float*)(zrow + 256 + 64);          // [scale BNA_CH][shift BNA_CH]
@@ -380,7 +381,10 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   }
   auto dma_weights = [&](unsigned char* slot, const int chunk_, const int j) __attribute__((always_inline)) {
     if ((ABL & 1) && !abl_first) return;
-    const bool k_absent = S2D && chunk_ * CC + kqB * 8 >= g.cg;       // (S2D: the last chunk may be partial)
+    // 64-channel chunks of a tensor whose channel count is not a multiple of 64 (464, 928: the mid-planes of layers 3 / 4;
+    // 240 in the S2D form): the last chunk's surplus channels read the bytes that follow the row's data -- the next row, or
+    // zeros past the tensor -- and meet ABSENT (zero) weights here
+    const bool k_absent = CC == 64 && chunk_ * CC + kqB * 8 >= g.cg;
     const unsigned koff = (CC == 64 ? ((j < NTAP && !k_absent) ? (unsigned)(j * g.cg) * 2u + kvoff[0] : ABSENT_K) : kvoff[j]) + (unsigned)(chunk_ * CC) * 2u;
     unsigned char* dst = slot + (8 * rwave) * 128;
 #pragma unroll
@@ -1234,16 +1238,17 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
   const bool shape_ok = conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre && !d.omap && d.drop_p == 0.f &&
                         g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 &&
                         g.ph == 1 && g.pw == 1 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && g.Gw + 1 <= HALO_WIDE &&
-                        d.K == 9 * g.cg && (g.cg % 64 == 0 || g.cg % 48 == 0) &&
+                        d.K == 9 * g.cg && (g.cg % 64 == 0 || g.cg % 48 == 0 || (g.cg % 8 == 0 && g.cg > 128 && pp_opt_win_partial)) &&
                         (long long)d.M * g.cstride < 0x7f000000LL && (!d.residual || d.ldr % 8 == 0);
   if (!shape_ok) return 1;
   const int n16 = (d.N + 15) / 16;
+  const bool c64 = g.cg % 64 == 0 || g.cg % 48 != 0;      // 64-channel chunks (the last one partial where cg % 64 != 0)
   if (g.Gw + 1 > HALO) {
     // frames 64..95 wide (the reference's own clips: layer 1 is 50 x 90): 96 rows of halo.  Two (256 + 192)-row windows of
     // 64-channel rows are 112 KB, so the wide tiles keep a TWO-slot weight ring (one K-step of flight for a weight slice);
     // the 48-channel data gradient keeps 256-row tiles (the 512-row tile's windows would be 154 KB)
     const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
-    if (g.cg % 64 == 0) {
+    if (c64) {
       if (n16 <= 4) return launch_win<4, 64, 2, 3, false, HALO_WIDE>(d, s);
       return c9 <= c8 ? launch_win<9, 64, 2, 2, false, HALO_WIDE>(d, s) : launch_win<8, 64, 2, 2, false, HALO_WIDE>(d, s);
     }
@@ -1251,7 +1256,7 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
     return c9 <= c8 ? launch_win<9, 48, 2, 2, false, HALO_WIDE>(d, s) : launch_win<8, 48, 2, 2, false, HALO_WIDE>(d, s);
   }
   // tile widths: 64 columns (narrow outputs) or 128 / 144 (whichever pads N less)
-  if (g.cg % 64 == 0) {
+  if (c64) {
     if (n16 <= 4) return launch_win<4, 64, 2, 3>(d, s);
     const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
     return c9 <= c8 ? launch_win<9, 64, 2, 3>(d, s) : launch_win<8, 64, 2, 3>(d, s);

@@ -103,6 +103,7 @@ def gather_conv(mode, R, G, k, s, p, cg, cstride):
     return g
 
 
+WIN_TALL_DEFAULT = 0       # pp_set_option("win_tall", n): 512-row window tiles for narrow-output data gradients (1: with enough rows, 2: always)
 WGRAD_GROUP_RING_DEFAULT = 0   # pp_set_option("wgrad_group_ring", 1): grouped Linear weight gradients on the ring kernel's 128 x 256 tiles
 RING_WGRAD_DEFAULT = 0     # pp_set_option("ring_wgrad", n): LDS-DMA ring weight gradient once M >= n rows (0 = never)
 SW_WGRAD_DEFAULT = 4096   # pp_set_option("sw_wgrad", n): sliding-window wgrad of (1,3,3) stride-1 convs once M >= n (0 = never)

@@ -983,6 +983,9 @@ def test_sliding_window_wgrad_matches_generic(case):
     (144, 64, 1, 1, 5, 95),       # widest supported image (W + 1 = 96); fwd 48-channel chunks -> 64 columns, dgrad 64 -> 144
     (128, 128, 1, 1, 4, 64),      # first width of the 96-row halo; 128-column tiles both ways
     (64, 45, 1, 1, 6, 70),        # narrow output from 64-channel chunks; dgrad from 48 padded channels
+    (256, 460, 1, 2, 14, 14),     # layer 3's mid-planes: the dgrad reduces over 464 channels = 7.25 chunks of 64 (partial last chunk)
+    (512, 921, 1, 1, 7, 7),       # layer 4's: 928 channels = 14.5 chunks
+    (208, 96, 1, 1, 9, 12),       # a forward from 208 channels (3.25 chunks) as well
 ])
 def test_window_igemm_matches_gather_igemm(case):
     """Window conv kernel (A halo window in LDS, taps = address offsets, zero row outside the image) against the
@@ -1011,7 +1014,7 @@ def test_window_igemm_matches_gather_igemm(case):
             outs.append((y.float(), st.clone(), dx.float(), dxr.float()))
     finally:
         H.set_option("win_igemm", H.WIN_IGEMM_DEFAULT)
-        H.set_option("win_tall", 1)
+        H.set_option("win_tall", H.WIN_TALL_DEFAULT)
     for a, b, name in list(zip(outs[0], outs[1], ("fwd", "colstats", "dgrad", "dgrad + residual"))) + \
             list(zip(outs[0], outs[2], ("fwd (tall)", "colstats", "dgrad (tall)", "dgrad + residual (tall)"))):
         assert a.shape == b.shape, name
@@ -1142,7 +1145,7 @@ def test_bn_backward_sums_in_the_dgrad_epilogue(case, tall):
         dxs = L.conv_dgrad(to_cl(torch.randn(32, 48, 2, 6, 6), small.out_cstride), small, wds, consumer=(ys, None, svs, True))
         assert not hasattr(dxs, "_bnr")
     finally:
-        H.set_option("win_tall", 1)
+        H.set_option("win_tall", H.WIN_TALL_DEFAULT)
         L.FUSE_BN_BWD_REDUCE = False
 
 

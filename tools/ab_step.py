@@ -94,7 +94,7 @@ def set_switch(name, on):
         raise SystemExit(f"unknown switch {name}")
 
 
-defaults = {"win_tall": True, "win_s2d": True, "wgrad_flat": True, "win_producers_all": True, "ring_producers": True, "win_producers_tw": True, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
+defaults = {"win_tall": False, "win_s2d": True, "wgrad_flat": True, "win_producers_all": True, "ring_producers": True, "win_producers_tw": True, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
 for _ in range(3):
     step(0)
 for name in sys.argv[1:]:
