@@ -244,9 +244,17 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 #endif
   // producer waves (PROD): two for the weight slices, two for the windows (tools/probe/win_prod_sweep.sh: three + one is
   // no better for the 128- / 144-column tiles and loses the 512-row tile's gain -- its windows are 70 pieces a phase)
+  // temporal form (resident weights, loaded once per workgroup): the two weight producers would idle after the prologue, so
+  // ALL FOUR producers issue window pieces (DUAL) -- one wave sustains ~13 GB/s of LDS-DMA (wgrad_tw.hip's measurement) and
+  // the kernel is HBM-bound.  (A single weight producer is not an option: a weight wave's pieces must lie 16 rows apart for
+  // its one precomputed swizzle to hold.)
+#ifndef PP_WIN_DUAL
+#define PP_WIN_DUAL 1
+#endif
   constexpr int NPB = TW ? 2 : PP_WIN_PROD_B, NPX = 4 - NPB;
+  constexpr bool DUAL = PROD && TW && PP_WIN_DUAL;
   constexpr int NWB = PROD ? NPB : NW / 2;                    // waves in the weight role
-  constexpr int NWX = PROD ? NPX : NW / 2;                    // waves in the window role
+  constexpr int NWX = PROD ? (DUAL ? 4 : NPX) : NW / 2;       // waves in the window role
   static_assert(!PROD || (!BNR && !STG), "producer waves: plain epilogue");
   constexpr int NWP = (WPIECES + NWX - 1) / NWX;              // window pieces per window wave and phase
   constexpr int NBI = (BN + 8 * NWB - 1) / (8 * NWB);         // weight pieces per weight wave and K-step (last one maybe absent)
@@ -273,10 +281,11 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // roles (wave-uniform)
   const bool is_comp = !PROD || wave < NW;
-  const bool win_wave = PROD ? wave >= NW + NPB : wave >= NWB;
+  const bool win_wave = PROD ? (DUAL ? wave >= NW : wave >= NW + NPB) : wave >= NWB;
   const bool wgt_wave = PROD ? (wave >= NW && wave < NW + NPB) : wave < NWB;
-  const int rwave = PROD ? (win_wave ? wave - NW - NPB : (wgt_wave ? wave - NW : 0))   // index inside the role
-                         : (win_wave ? wave - NWB : wave);
+  // index inside the role (a DUAL producer has both)
+  const int rwave_x = PROD ? (DUAL ? wave - NW : (win_wave ? wave - NW - NPB : 0)) : (win_wave ? wave - NWB : 0);
+  const int rwave_b = PROD ? (wgt_wave ? wave - NW : 0) : (wgt_wave ? wave : 0);
   const int fr = lane & 15, fq = lane >> 4;
   const int G = gridDim.x, bid = blockIdx.x;
   auto tile_index = [&](int it) __attribute__((always_inline)) -> int {   // persistent walk, XCD-contiguous (igemm.hip)
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   unsigned w_voff[NVO];
 #pragma unroll
   for (int k = 0; k < NVO; ++k) {
-    const int q = rwave + NWX * k;
+    const int q = rwave_x + NWX * k;
     int row, cb;
     if (CC == 64) {
       row = q * 8 + (lane >> 3);
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   const unsigned w_step = WLIN ? (unsigned)(8 * NWX * g.cstride * 2) : 0u;   // bytes between a wave's consecutive pieces
   // temporal form with a halo (kept only as staging room for wide outputs): its pieces are never read, so never fetched
   auto piece_live = [&](const int k) __attribute__((always_inline)) -> bool {
-    const int q = rwave + NWX * k;
+    const int q = rwave_x + NWX * k;
     if (TW && HALO_ > 0) return q * 1024 >= HALO_ * XS && (q + 1) * 1024 <= (HALO_ + BM) * XS;
     return q < WPIECES;
   };
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     return (unsigned)(row0 * g.cstride + chunk_ * CC) * 2u;
   };
   auto dma_window_piece = [&](const int k, unsigned char* wbuf, const unsigned sbase) __attribute__((always_inline)) {
-    const int q = rwave + NWX * k;
+    const int q = rwave_x + NWX * k;
     if ((ABL & 2) && !abl_first) return;
     if (piece_live(k)) lds_dma16(rsA, wbuf + q * 1024, WLIN ? sbase + (unsigned)k * w_step + w_voff[0] : sbase + w_voff[k]);
   };
@@ -360,14 +369,81 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   int npieces = 0;
 #pragma unroll
   for (int k = 0; k < NWP; ++k) npieces += piece_live(k) ? 1 : 0;
+  // PBNA: the fused BatchNorm apply (BNA) done by the PRODUCER waves.  Round 2's form has the eight multiplying waves run
+  // an LDS pass over each window between two barriers of their own (+100 us on the layer-1 temporal forward: 414 vs 314 us).
+  // Here every producer activates exactly the 16-byte slots it fetched itself -- its pieces of the NEXT phase's window, as
+  // soon as its own vmcnt says they have landed, while the multiplying waves are in the current phase's K-steps: no wave
+  // reads another wave's DMA results, so no barrier is added, and the multiplying waves never see a raw window.
+  // MEASURED (round 4, tools/probe/bna_tw.py, bit-identical outputs): 461-467 us against 414 us -- four producer waves that also
+  // run the LDS pass (seven 16-byte slots per lane and phase: five reads + a write each) are late with the next window's DMAs
+  // and become the critical path of a phase whose three K-steps are short.  Built only with -DPP_WIN_PBNA=1.
+#ifndef PP_WIN_PBNA
+#define PP_WIN_PBNA 0
+#endif
+  constexpr bool PBNA = PP_WIN_PBNA && BNA && PROD && DUAL && NWIN == 3;
+  constexpr int SPR = XS / 16;                               // 16-byte slots per window row (the last one is padding)
+  int bna_c8[PBNA ? NWP : 1];
+  if (PBNA) {
+#pragma unroll
+    for (int k = 0; k < NWP; ++k) {
+      const int q = rwave_x + NWX * k;
+      const int c8 = (q * 64 + lane) % SPR;
+      bna_c8[k] = (q < WPIECES && c8 < CC / 8) ? c8 : -1;
+    }
+  }
+  auto bna_own = [&](unsigned char* wbuf, const int chunk_) __attribute__((always_inline)) {
+    if constexpr (PBNA) {
+      constexpr int NB1 = (NWP + 1) / 2;                       // two batches: all reads of a batch, one wait, the writes
+#pragma unroll
+      for (int b0 = 0; b0 < NWP; b0 += NB1) {
+        u32x4 vv[NB1], s0[NB1], s1[NB1], h0[NB1], h1[NB1];
+        unsigned adr[NB1];
+#pragma unroll
+        for (int k = b0; k < b0 + NB1 && k < NWP; ++k) {
+          const int c8 = bna_c8[k] < 0 ? 0 : bna_c8[k];
+          adr[k - b0] = (unsigned)(uintptr_t)(lds_ptr)(wbuf + (rwave_x + NWX * k) * 1024 + lane * 16);
+          const unsigned t = (unsigned)(uintptr_t)(lds_ptr)(bna_tab + chunk_ * CC + c8 * 8);
+          asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
+                       "ds_read_b128 %3, %6 offset:%7\n\tds_read_b128 %4, %6 offset:%8"
+                       : "=&v"(vv[k - b0]), "=&v"(s0[k - b0]), "=&v"(s1[k - b0]), "=&v"(h0[k - b0]), "=&v"(h1[k - b0])
+                       : "v"(bna_c8[k] < 0 ? (unsigned)(uintptr_t)(lds_ptr)zrow : adr[k - b0]), "v"(t), "n"(BNA_CH * 4), "n"(BNA_CH * 4 + 16)
+                       : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NB1; ++k) asm volatile("" : "+v"(vv[k]), "+v"(s0[k]), "+v"(s1[k]), "+v"(h0[k]), "+v"(h1[k]));
+#pragma unroll
+        for (int k = b0; k < b0 + NB1 && k < NWP; ++k) {
+          if (bna_c8[k] >= 0) {
+            const int i = k - b0;
+            float x[8];
+            unpack8(make_uint4(vv[i][0], vv[i][1], vv[i][2], vv[i][3]), x);
+            const float sc[8] = {__uint_as_float(s0[i][0]), __uint_as_float(s0[i][1]), __uint_as_float(s0[i][2]), __uint_as_float(s0[i][3]),
+                                 __uint_as_float(s1[i][0]), __uint_as_float(s1[i][1]), __uint_as_float(s1[i][2]), __uint_as_float(s1[i][3])};
+            const float sh[8] = {__uint_as_float(h0[i][0]), __uint_as_float(h0[i][1]), __uint_as_float(h0[i][2]), __uint_as_float(h0[i][3]),
+                                 __uint_as_float(h1[i][0]), __uint_as_float(h1[i][1]), __uint_as_float(h1[i][2]), __uint_as_float(h1[i][3])};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const float zv = x[q] * sc[q] + sh[q];
+              x[q] = (p.bna_relu && !(zv > 0.f)) ? 0.f : zv;
+            }
+            const uint4 o = pack8(x);
+            const u32x4 ov = {o.x, o.y, o.z, o.w};
+            asm volatile("ds_write_b128 %0, %1" ::"v"(adr[i]), "v"(ov) : "memory");
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
   // ---- weight DMA (waves 0..3): rows 8 wave + (lane >> 3) + 32 i, slot lane & 7 holds K chunk (lane & 7) ^ swz(row).
   // Source offset = row part (per tile) + K part of the K-step (per workgroup; flat (tap, channel) K inside a chunk, so a
   // 48-channel chunk's K-step straddles taps and the part is per lane) + chunk (scalar).  0x80000000 marks "absent"
   // (row past the matrix, K past the last tap): the sum stays beyond the resource's size and zeros land. ------------
   constexpr unsigned ABSENT = 0x80000000u, ABSENT_K = 0x40000000u;   // (their sum does not wrap; Bt is < 2^30 bytes)
-  const int brow0 = 8 * rwave + (lane >> 3);
+  const int brow0 = 8 * rwave_b + (lane >> 3);
   const int kqB = (lane & 7) ^ swz(brow0);
-  const bool b_last = 8 * rwave + 8 * NWB * (NBI - 1) < BN;   // does this wave own a piece in the last weight pass
+  const bool b_last = 8 * rwave_b + 8 * NWB * (NBI - 1) < BN;   // does this wave own a piece in the last weight pass
   const int nB = b_last ? NBI : NBI - 1;
   unsigned bvoff[NBI];
   // (64-channel chunks: K-step j is tap j, channels kqB * 8 ..: the lane's part moves into the row offset)
@@ -386,7 +462,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
     // zeros past the tensor -- and meet ABSENT (zero) weights here
     const bool k_absent = CC == 64 && chunk_ * CC + kqB * 8 >= g.cg;
     const unsigned koff = (CC == 64 ? ((j < NTAP && !k_absent) ? (unsigned)(j * g.cg) * 2u + kvoff[0] : ABSENT_K) : kvoff[j]) + (unsigned)(chunk_ * CC) * 2u;
-    unsigned char* dst = slot + (8 * rwave) * 128;
+    unsigned char* dst = slot + (8 * rwave_b) * 128;
 #pragma unroll
     for (int i = 0; i < NBI; ++i)
       if (i < NBI - 1 || b_last) lds_dma16(rsB, dst + 8 * NWB * i * 128, bvoff[i] + koff);
@@ -856,8 +932,17 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   constexpr int LA = RW ? 0 : NBS - 1;                          // weight K-steps in flight ahead of the multiply
   constexpr int PPK = TW ? NWP : (NWP + NKC - 1) / NKC;       // window pieces per window wave and K-step
   int last_win = 0;                   // window pieces this (window) wave issued at the previous phase start
-  if (!DMA) {
-  } else if (win_wave) {
+  if (DMA && wgt_wave) {
+    if (RW) {
+      for (int c = 0; c < nchunk; ++c)      // (the launcher checked S <= NBS; same N block for every tile)
+#pragma unroll
+        for (int j = 0; j < NKC; ++j) dma_weights(bring + (c * NKC + j) * B_BYTES, c, j);
+    } else {
+#pragma unroll
+      for (int a = 0; a < LA; ++a) dma_weights(bring + a * B_BYTES, 0, a);      // (NKC >= 6 > LA)
+    }
+  }
+  if (DMA && win_wave) {        // (a DUAL producer: after its share of the resident weights; the first wait drains both)
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       unsigned sb = 0;
@@ -868,14 +953,10 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         last_win = npieces;
       }
     }
-  } else if (!wgt_wave) {
-  } else if (RW) {
-    for (int c = 0; c < nchunk; ++c)      // (the launcher checked S <= NBS; same N block for every tile)
-#pragma unroll
-      for (int j = 0; j < NKC; ++j) dma_weights(bring + (c * NKC + j) * B_BYTES, c, j);
-  } else {
-#pragma unroll
-    for (int a = 0; a < LA; ++a) dma_weights(bring + a * B_BYTES, 0, a);      // (NKC >= 6 > LA)
+    if (PBNA) {       // window 0 (and this wave's resident weights) have landed once only window 1 is in flight
+      wait_vmcnt_dyn(last_win);
+      bna_own(smem, 0);
+    }
   }
   int last_batch = 0;                 // weight DMAs this (weight) wave issued in the previous iteration
 #if PP_WIN_ABLATE & 64
@@ -911,6 +992,9 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
       unsigned char* const nwin = smem + (wsel + D >= NWIN ? wsel + D - NWIN : wsel + D) * WIN_BYTES;   // of the phase D ahead
       unsigned nbase = 0;
       const bool nvalid = DMA && win_wave && phase_ahead(it, chunk, D, tile, nbase);
+      unsigned nbase1 = 0;
+      const bool nvalid1 = PBNA && DMA && win_wave && phase_ahead(it, chunk, 1, tile, nbase1);    // is there a next phase
+      unsigned char* const win1 = smem + (wsel + 1 >= NWIN ? wsel + 1 - NWIN : wsel + 1) * WIN_BYTES;
 #pragma unroll
       for (int j = 0; j < NKC; ++j) {
         // weight waves, three slots: everything but the batch of the previous iteration (the weights of step s + 1) must
@@ -928,7 +1012,8 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         drain = false;
         PP_STAMP(0)
         if (!RW || j == 0) __builtin_amdgcn_s_barrier();
-        if (BNA && j == 0 && !COMP) {        // (producer waves: only the pass's closing barrier)
+        if (PBNA) {                          // (the producers activated this window during the previous phase)
+        } else if (BNA && j == 0 && !COMP) {        // (producer waves: only the pass's closing barrier)
           __builtin_amdgcn_s_barrier();
         } else if (BNA && j == 0) {
           // z = relu(y * scale + shift) on the window that has just landed: 256 rows x six 8-channel octets, three per
@@ -990,6 +1075,10 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 #pragma unroll
                   for (int k = 0; k < NWP; ++k) dma_window_piece(k, nwin, nbase);
                   last_win = npieces;
+                }
+                if (PBNA && nvalid1) {   // the next phase's window has landed once only the one just issued is in flight
+                  wait_vmcnt_dyn(last_win);
+                  bna_own(win1, chunk + 1 < nchunk ? chunk + 1 : 0);
                 }
               }
             } else if (nvalid) {

@@ -35,6 +35,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29541")
 os.environ.setdefault("RANK", "0")
 os.environ.setdefault("WORLD_SIZE", "1")
+os.environ["PEPPA_FORCE_DIST"] = "1"      # one rank, every collective live (peppa_amd.dist.is_dist)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl")
 
@@ -55,11 +56,14 @@ marks = {}          # bucket name -> [event per step]
 orig_launch = PD.GradBuckets._launch
 
 
+STEP = [0]
+
+
 def launch(self, b):
     orig_launch(self, b)
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()      # on the stream of the last arrival, behind the packing copies and the collective's enqueue
-    marks.setdefault(b["name"], []).append(ev)
+    marks.setdefault(b["name"], []).append((STEP[0], ev, len(b["pushed"]), len(b["params"])))
 
 
 PD.GradBuckets._launch = launch
@@ -68,6 +72,7 @@ for i in range(args.warmup + args.steps):
     if i == args.warmup:
         marks.clear()
     opt.zero_grad(set_to_none=True)
+    STEP[0] = i - args.warmup
     e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     e[0].record()
     loss = net.training_step(batch, i)
@@ -84,14 +89,13 @@ n = len(steps)
 fwd = sum(e[0].elapsed_time(e[1]) for e in steps) / n
 bwd = sum(e[1].elapsed_time(e[2]) for e in steps) / n
 tot = sum(e[0].elapsed_time(e[3]) for e in steps) / n
-rows = []
+rows, early = [], {}
 for b in buckets.buckets:
-    evs = marks.get(b["name"], [])
+    evs = [m for m in marks.get(b["name"], []) if 0 <= m[0] < n]
     mb = b["flat"].numel() * 4 / 1e6
-    if len(evs) < n:      # (LayerDrop: a layer's bucket is reduced in finish() in the steps that skip it)
-        when = float("nan") if not evs else sum(steps[k][1].elapsed_time(ev) for k, ev in enumerate(evs[:n])) / len(evs[:n])
-    else:
-        when = sum(steps[k][1].elapsed_time(evs[k]) for k in range(n)) / n
+    # (LayerDrop: a layer's bucket is reduced in finish() in the steps that skip it -- those steps carry no mark)
+    when = sum(steps[k][1].elapsed_time(ev) for k, ev, _, _ in evs) / len(evs) if evs else float("nan")
+    early[b["name"]] = (sum(m[2] for m in evs) / max(1, len(evs)), len(b["params"]), len(evs))
     t_ar = args.latency_us * 1e-3 + 2.0 * (args.world - 1) / args.world * mb * 1e6 / (args.bw * 1e9) * 1e3
     rows.append((when, b["name"], mb, t_ar))
 rows.sort(key=lambda r: (r[0] != r[0], r[0]))
@@ -103,16 +107,16 @@ lines = ["# Gradient buckets: when each is complete in the backward pass, and it
          f"was).  Modelled all-reduce: {args.latency_us:.0f} us + 2 x 7/8 x bytes / {args.bw:.0f} GB/s (ring over xGMI, {args.world} ranks; "
          "assumption, see the tool's docstring) -- **no 1 -> 8 curve was measured**.  The collectives run on RCCL's own stream, one after "
          "the other: 'done' = max(complete, previous done) + its time; slack = end of backward - done.\n",
-         "| bucket | MB | complete (ms) | modelled all-reduce (ms) | modelled done (ms) | slack to the end of backward (ms) |", "|---|---|---|---|---|---|"]
+         "| bucket | MB | tensors handed over early / all | steps it was complete in backward | complete (ms) | modelled all-reduce (ms) | modelled done (ms) | slack to the end of backward (ms) |", "|---|---|---|---|---|---|---|---|"]
 done = 0.0
 total_mb, exposed = 0.0, 0.0
 for when, name, mb, t_ar in rows:
     total_mb += mb
     start = max(done, when) if when == when else done
     done = start + t_ar
-    lines.append(f"| {name} | {mb:.1f} | {when:.2f} | {t_ar:.3f} | {done:.2f} | {bwd - done:.2f} |")
+    lines.append(f"| {name} | {mb:.1f} | {early[name][0]:.0f} / {early[name][1]} | {early[name][2]} / {n} | {when:.2f} | {t_ar:.3f} | {done:.2f} | {bwd - done:.2f} |")
 exposed = max(0.0, done - bwd)
-lines.append(f"| **all** | **{total_mb:.0f}** | | **{sum(r[3] for r in rows):.2f}** | {done:.2f} | {bwd - done:.2f} |\n")
+lines.append(f"| **all** | **{total_mb:.0f}** | | | | **{sum(r[3] for r in rows):.2f}** | {done:.2f} | {bwd - done:.2f} |\n")
 lines.append(f"Reading: {total_mb:.0f} MB of gradients per rank take {sum(r[3] for r in rows):.1f} ms of modelled all-reduce inside a {bwd:.1f} ms backward pass; "
              f"the last bucket is done {('%.2f ms AFTER' % exposed) if exposed > 0 else ('%.2f ms before' % (bwd - done))} the backward pass ends"
              f"{'' if exposed > 0 else ' (nothing exposed)'}.  Predicted 8-GPU step = this one-rank step with the collectives live ({tot:.2f} ms) "
