@@ -215,23 +215,37 @@ def main():
         return
     ms = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
+    cfg_base = os.path.basename(args.config) == "hparams_base.yaml"
     # dominant kernel: HIP events recorded around its launches inside the timed region
     roof = H.profile_summary()
     roof_obj = None
     if roof:
         flops, secs, n, name = roof
         ach = flops / secs / 1e12
-        traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/), when this family was profiled
+        # HBM bytes from the COMMITTED PMC passes under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs;
+        # not measured inside this run -- `traffic_source` says which table): `traffic` = this kernel shape's bytes per
+        # launch, `step_hbm_bytes` = every launch of one training step (tools/prof_step_traffic.py), only for the workload
+        # the tables were taken on (configs[1], batch 64)
+        traffic = step_bytes = src = None
         try:
-            for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+            for fn in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
                 path = os.path.join(ROOT, "profiles", fn)
                 if traffic is None and os.path.exists(path):
                     traffic = json.load(open(path)).get(name)
+                    src = "profiles/" + fn if traffic is not None else None
+            acct = os.path.join(ROOT, "profiles", "r04_step_hbm_account.json")
+            if os.path.exists(acct) and (args.frames, args.size, args.samples, args.batch) == (16, 112, 36800, 64) and cfg_base:
+                step_bytes = json.load(open(acct))["step_bytes"]
         except Exception:
             pass
         roof_obj = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                     "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4), "traffic": traffic, "kernel": name,
                     "launches": n, "avg_us": round(secs / n * 1e6, 1)}
+        if src:
+            roof_obj["traffic_source"] = src + " (committed rocprofv3 PMC table, per launch; not collected in this run)"
+        if step_bytes:
+            roof_obj["step_hbm_bytes"] = step_bytes
+            roof_obj["step_hbm_frac_of_step_at_6.3TBps"] = round(step_bytes / 6.3e12 / (ms * 1e-3), 3)
         # In the timed region this kernel shares the chip with the audio tower and the weight-gradient stream, which
         # stretches its launches.  One extra untimed step with the side streams off gives its duration alone.
         iso = None

@@ -138,6 +138,11 @@ typedef struct pp_igemm_desc {
 int pp_igemm(const pp_igemm_desc* d, pp_stream_t s);
 /* 1 if pp_igemm would run `d` (sizes, gather, epilogue; pointers are not looked at) with a_bn_scale / a_bn_shift, else 0 */
 int pp_igemm_abn_supported(const pp_igemm_desc* d);
+/* rows of `colstats` ([rows][2][ldstat] fp32 partial column sums) pp_igemm writes for `d` -- what the caller allocates and
+ * pp_bn_finalize then reduces: one per 128 output rows, except where the temporal window kernel takes the problem with a frame
+ * count / frame size that does not tile evenly (two per TILE of 256 / T positions x all frames: a few more).  Set every
+ * field pp_igemm will see (colstats may be any non-null value). */
+long long pp_igemm_stat_rows(const pp_igemm_desc* d);
 
 /* dW[Ni,Kj] += sum_m dY[m,Ni]^T * X_gather[m,Kj]  (weight gradients; fp32 atomics).
  * Replaces autograd's conv/linear weight-gradient for the same modules. dW must be zeroed. */

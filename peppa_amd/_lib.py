@@ -74,6 +74,7 @@ SIGNATURES = {
     "pp_wgrad": [C.POINTER(WGradDesc), P],
     "pp_wgrad_ws_floats": [C.POINTER(WGradDesc)],
     "pp_igemm_abn_supported": [C.POINTER(IGemmDesc)],
+    "pp_igemm_stat_rows": [C.POINTER(IGemmDesc)],
     "pp_wgrad_xbn_supported": [C.POINTER(WGradDesc)],
     "pp_prep_conv_weight": [P, I, I, I, P, I, I, I, I, F, P],
     "pp_select_taps": [P, I, I, I, C.POINTER(I), I, P, P],
@@ -141,7 +142,7 @@ SIGNATURES = {
     "pp_triplet_accuracy": [P, P, P, I, I, I, P, P],
     "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P, P, P],
 }
-_RESTYPE = {"pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z, "pp_wgrad_ws_floats": L}
+_RESTYPE = {"pp_igemm_stat_rows": L, "pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z, "pp_wgrad_ws_floats": L}
 _NO_STATUS = set(_RESTYPE) | {"pp_version", "pp_dtype", "pp_experimental_build"}
 
 _libs = {}

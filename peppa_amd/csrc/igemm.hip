@@ -40,6 +40,7 @@ int pp_opt_xcd_remap_wgrad = 1;
 int pp_opt_wgrad_flat = 1;
 int pp_opt_win_s2d = 1;
 int pp_opt_win_partial = 1;
+int pp_opt_win_ragged = 1;
 int pp_opt_wgrad_group_ring = 0;
 // BatchNorm streaming passes (tools/bench_bn.py, layer-1 shapes): non-temporal STORES + 32 k workgroups instead of plain
 // stores + 4 k: apply 417 -> 370 us, backward apply 576 -> 485 us at 144 channels (4.4 / 4.8 -> 5.0 / 5.7 TB/s); non-temporal
@@ -77,6 +78,7 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "wgrad_flat")) { pp_opt_wgrad_flat = value; return PP_OK; }
   if (!strcmp(name, "win_s2d")) { pp_opt_win_s2d = value; return PP_OK; }
   if (!strcmp(name, "win_partial")) { pp_opt_win_partial = value; return PP_OK; }
+  if (!strcmp(name, "win_ragged")) { pp_opt_win_ragged = value; return PP_OK; }
   if (!strcmp(name, "wgrad_group_ring")) { pp_opt_wgrad_group_ring = value; return PP_OK; }
   if (!strcmp(name, "bn_nt")) { pp_opt_bn_nt = value; return PP_OK; }
   if (!strcmp(name, "win_out_nt")) { pp_opt_win_out_nt = value; return PP_OK; }
@@ -87,6 +89,7 @@ extern "C" int pp_set_option(const char* name, int value) {
 
 int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s);
 int pp_igemm_abn_ok(const pp_igemm_desc& d);
+long long pp_igemm_win_stat_rows(const pp_igemm_desc& d);
 
 namespace {
 
@@ -828,6 +831,15 @@ extern "C" int pp_igemm_abn_supported(const pp_igemm_desc* dp) {
   if (d.nbatch <= 0) d.nbatch = 1;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || pp_validate_gather(d.g, d.K, "pp_igemm_abn_supported") != PP_OK) return 0;
   return pp_igemm_abn_ok(d);
+}
+
+extern "C" long long pp_igemm_stat_rows(const pp_igemm_desc* dp) {
+  if (!dp || dp->M <= 0) return 0;
+  pp_igemm_desc d = *dp;
+  if (d.b_rows <= 0) d.b_rows = d.N;
+  if (d.nbatch <= 0) d.nbatch = 1;
+  if (d.g.mode == PP_DENSE || pp_validate_gather(d.g, d.K, "pp_igemm_stat_rows") != PP_OK) return ((long long)d.M + 127) / 128;
+  return pp_igemm_win_stat_rows(d);
 }
 
 extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {

@@ -26,6 +26,7 @@ extern int pp_opt_win_stagger;
 extern int pp_opt_win_producers;
 extern int pp_opt_win_s2d;
 extern int pp_opt_win_partial;
+extern int pp_opt_win_ragged;
 
 // Timing ablations for tools/probe/win_ablate.py (results are WRONG with any bit set; the shipped library has 0):
 // 1 weights only for a workgroup's first tile, 2 windows likewise, 4 no fragment reads / MFMAs, 8 no epilogue,
@@ -152,8 +153,10 @@ struct WinGeom {
   int cg;        // A channels per tap (= K / 9)
   int sign;      // +1 forward, -1 data gradient (source = m - off)
   // temporal (3,1,1) variant: a tile is ALL T frames of PB = BM / T consecutive positions of one clip
-  FastDiv dBlk;  // position blocks per clip (H*W / PB)
-  int nblk, T, HW, PB, pshift;
+  FastDiv dBlk;  // position blocks per clip (ceil(H*W / PB): the last one may be ragged)
+  FastDiv dPB;   // tile row -> (frame, position): frame = lr / PB
+  int nblk, T, HW, PB;
+  int nstat;     // partial rows of column statistics the launch writes (two per tile)
   FastDiv dNb;   // column blocks per row block (tile -> (row block, column block))
   int oH, oW;    // S2D: the (H, W) of dx; W, H above are then those of dy
   int Mout;      // S2D: rows of dx
@@ -310,8 +313,13 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   }
   __syncthreads();
   auto tw_row = [&](const int tile_m, const int lr) __attribute__((always_inline)) -> int {   // global row of tile row lr
+    // (any frame count 2..32 since round 4: PB = 256 / T positions per tile, so up to T - 1 tile rows lie past frame T - 1,
+    // and the last position block of a clip may reach past H*W: both kinds of row are dead -- no taps (setup_tile), no
+    // store (the sentinel g.M fails every `m < g.M`), and no live row ever reads them as a tap)
     const int b = (int)fdiv((uint32_t)tile_m, g.dBlk);
-    return (b * g.T + (lr >> g.pshift)) * g.HW + (tile_m - b * g.nblk) * g.PB + (lr & (g.PB - 1));
+    const int frame = (int)fdiv((uint32_t)lr, g.dPB);
+    const int pos = (tile_m - b * g.nblk) * g.PB + (lr - frame * g.PB);
+    return (frame < g.T && pos < g.HW) ? (b * g.T + frame) * g.HW + pos : g.M;
   };
 
   // ---- window DMA: piece q = rwave + 4 k lands 1 KiB lane-linear.  Everything that depends on the lane is one byte
@@ -337,7 +345,8 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
       cb = o - row * XS;
     }
     const int lr = row - HB;
-    const int rel = TW ? (lr >> g.pshift) * g.HW + (lr & (g.PB - 1)) : lr;
+    const int lfr = TW ? (int)fdiv((uint32_t)(lr < 0 ? 0 : lr), g.dPB) : 0;
+    const int rel = TW ? lfr * g.HW + (lr - lfr * g.PB) : lr;
     w_voff[k] = (unsigned)(rel * g.cstride * 2 + cb);
   }
   const unsigned w_step = WLIN ? (unsigned)(8 * NWX * g.cstride * 2) : 0u;   // bytes between a wave's consecutive pieces
@@ -483,11 +492,14 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (TW) {
-        const int frame = (wave * (16 * MT) + mt * 16 + fr) >> g.pshift;
+        const int lr = wave * (16 * MT) + mt * 16 + fr;
+        const int frame = (int)fdiv((uint32_t)lr, g.dPB);
+        const int b = (int)fdiv((uint32_t)mb, g.dBlk);
+        const bool live = frame < g.T && (mb - b * g.nblk) * g.PB + (lr - frame * g.PB) < g.HW;     // (dead rows: see tw_row)
         unsigned v = 0;
 #pragma unroll
         for (int t = 0; t < 3; ++t) v |= (unsigned)((unsigned)(frame + g.sign * (t - 1)) < (unsigned)g.T) << t;
-        vmask[mt] = v;                     // (M is a whole number of tiles)
+        vmask[mt] = live ? v : 0u;
         continue;
       }
       const int m = mb * BM + wave * (16 * MT) + mt * 16 + fr;
@@ -885,7 +897,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         const int c = idx % BN, h = idx / BN;
         const int n = nb_e * BN + c;
         const long long prow = (long long)mb_e * (NW / 4) + h;
-        if (n < p.ldstat && prow * 128 < g.M) {
+        if (n < p.ldstat && prow < g.nstat) {
           float a = 0.f, b = 0.f;
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
@@ -1169,9 +1181,8 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   g.dW_ = make_fastdiv((uint32_t)gg.Gw);
   g.dH_ = make_fastdiv((uint32_t)gg.Gh);
   g.T = gg.Gt; g.HW = gg.Gh * gg.Gw; g.PB = TW ? BM / gg.Gt : 1;
-  g.pshift = 0;
-  while ((1 << g.pshift) < g.PB) ++g.pshift;
-  g.nblk = g.HW / g.PB;
+  g.dPB = make_fastdiv((uint32_t)g.PB);
+  g.nblk = (g.HW + g.PB - 1) / g.PB;
   g.dBlk = make_fastdiv((uint32_t)(g.nblk > 0 ? g.nblk : 1));
   const int nblk_n = (d.N + BN - 1) / BN;
   g.dNb = make_fastdiv((uint32_t)nblk_n);
@@ -1188,7 +1199,9 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   const long long b_bytes = (((long long)d.b_rows - 1) * d.ldb + d.K) * 2;
   if (b_bytes <= 0 || b_bytes >= 0x40000000LL) { pp_set_error("pp_igemm: weight matrix too large for the window kernel"); return PP_ERR_INVALID; }
   a.b_bytes = (unsigned)b_bytes;
-  const long long nblk_m = ((long long)g.M + BM - 1) / BM;
+  const long long nblk_m = TW ? (long long)(d.M / ((long long)gg.Gt * g.HW)) * g.nblk : ((long long)g.M + BM - 1) / BM;
+  g.nstat = TW ? (int)(nblk_m * (BM / 128)) : (int)(((long long)g.M + 127) / 128);   // (spatial: rows [128 r, 128 r + 128) that exist)
+  const bool ragged = TW && (g.HW % g.PB != 0 || gg.Gt * g.PB != BM);    // dead rows inside tiles: no BatchNorm-backward sums in the epilogue
   const long long ntiles = nblk_m * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
   const long long gx = ntiles < pp_opt_persist_cus ? ntiles : pp_opt_persist_cus;
@@ -1210,7 +1223,7 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
     return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
   } else {
   if constexpr (TW) {
-    if (pp_opt_win_producers >= 3 && !(d.bnr_partials && bnr_built<WN, CC, MT, TW>())) {     // (3: also the temporal form)
+    if (pp_opt_win_producers >= 3 && !(d.bnr_partials && !ragged && bnr_built<WN, CC, MT, TW>())) {     // (3: also the temporal form)
       dim3 pblock(NT + 256);
       if (bna) {
         if constexpr (CC == 48) {
@@ -1239,7 +1252,7 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
     }
   }
   if constexpr (bnr_built<WN, CC, MT, TW>()) {
-    if (d.bnr_partials) {
+    if (d.bnr_partials && !ragged) {
       if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
       else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
       PP_LAUNCH_CHECK();
@@ -1284,11 +1297,14 @@ extern "C" int pp_debug_win_stamps(void* host_out) {
 static bool tw_shape_ok(const pp_igemm_desc& d) {
   const pp_gather& g = d.g;
   const bool conv = g.mode == PP_CONV_FWD || g.mode == PP_CONV_DGRAD;
-  const int pb = (g.Gt == 4 || g.Gt == 8 || g.Gt == 16 || g.Gt == 32) ? 256 / g.Gt : 0;
+  // 2..32 frames (round 4; was 4 / 8 / 16 / 32 with H*W a multiple of 256 / T): PB = 256 / T positions per tile, dead rows masked
+  const bool pow2 = g.Gt == 4 || g.Gt == 8 || g.Gt == 16 || g.Gt == 32;
+  const bool even = pow2 && (g.Gh * g.Gw) % (256 / g.Gt) == 0 && d.M % 256 == 0;
+  const long long rows = (long long)g.Gt * g.Gh * g.Gw;
   return conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && d.drop_p == 0.f &&
          !d.Cpre && !d.omap && g.kt == 3 && g.kh == 1 && g.kw == 1 && g.st == 1 && g.sh == 1 && g.sw == 1 &&
-         g.pt == 1 && g.ph == 0 && g.pw == 0 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && pb > 0 &&
-         (g.Gh * g.Gw) % pb == 0 && d.K == 3 * g.cg && d.M % 256 == 0 &&
+         g.pt == 1 && g.ph == 0 && g.pw == 0 && g.Gt == g.Rt && g.Gh == g.Rh && g.Gw == g.Rw && g.Gt >= 2 && g.Gt <= 32 &&
+         (even || pp_opt_win_ragged) && d.K == 3 * g.cg && d.M % rows == 0 &&
          (long long)d.M * g.cstride < 0x7f000000LL && (!d.residual || d.ldr % 8 == 0);
 }
 
@@ -1299,6 +1315,21 @@ int pp_igemm_abn_ok(const pp_igemm_desc& d) {
   const int n16 = (d.N + 15) / 16;
   return pp_opt_win_igemm && (long long)d.M >= pp_opt_win_igemm && pp_opt_win_temporal && g.mode == PP_CONV_FWD && tw_shape_ok(d) &&
          !d.residual && !d.bnr_partials && (g.cg == 48 || g.cg == 144) && n16 <= 4;
+}
+
+// Partial rows of column statistics ([rows][2][ldstat] fp32) pp_igemm writes for `d`: one per 128 output rows, except the
+// temporal window form, whose tiles are all frames of 256 / T positions -- two rows per TILE, and with a frame count or
+// frame size that does not divide evenly there are more tiles than M / 256.  Mirrors pp_igemm_win_try's dispatch.
+long long pp_igemm_win_stat_rows(const pp_igemm_desc& d) {
+  const pp_gather& g = d.g;
+  const long long dflt = ((long long)d.M + 127) / 128;
+  if (!(pp_opt_win_igemm && (long long)d.M >= pp_opt_win_igemm && pp_opt_win_temporal && tw_shape_ok(d))) return dflt;
+  const int n16 = (d.N + 15) / 16;
+  const bool taken = (g.cg == 64 && n16 <= 4) || (g.cg == 64 && n16 <= 9 && !d.colstats) || (g.cg == 48 && n16 <= 4) || (g.cg == 144 && n16 <= 4);
+  if (!taken) return dflt;
+  const int pb = 256 / g.Gt;
+  const long long nblk = ((long long)g.Gh * g.Gw + pb - 1) / pb;
+  return (long long)d.M / ((long long)g.Gt * g.Gh * g.Gw) * nblk * 2;
 }
 
 // PP_OK if the window kernel took the problem, 1 if the shape is not one it handles (caller falls through), < 0 on error.

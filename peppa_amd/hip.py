@@ -206,6 +206,16 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
     return bnr is not None and rc[0] == 0
 
 
+def igemm_stat_rows(M, N, K, g, *, bna=False):
+    """Rows of the BatchNorm partial-statistics buffer a plain conv-forward pp_igemm of these sizes writes (pp_igemm_stat_rows)."""
+    d = IGemmDesc()
+    d.M, d.N, d.K, d.g, d.b_rows, d.nbatch = M, N, K, g, N, 1
+    d.colstats = 1          # (any non-null value: only asks "with statistics")
+    if bna:
+        d.a_bn_scale = d.a_bn_shift = 1
+    return int(_lib.lib().pp_igemm_stat_rows(C.byref(d)))
+
+
 def igemm_abn_supported(M, N, K, g, *, colstats=True):
     """Would pp_igemm take a plain conv-forward of these sizes with a producer BatchNorm applied to A (igemm(bna=...))?"""
     d = IGemmDesc()

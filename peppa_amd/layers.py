@@ -205,7 +205,12 @@ def conv_fwd(x, geom, wf, *, stats=False, bias=None, act=H.ACT_NONE, out=None, p
     """y[M][out_cstride] = conv(x); optional per-column partial sums for BatchNorm.
     x_bn = (scale, shift, relu): x is the raw output of a BatchNorm unit whose apply pass was skipped (can_fuse_bn_apply)."""
     y = out if out is not None else empty((geom.M, geom.out_cstride), act16(), x)
-    partials = empty((geom.nblk, 2, geom.out_cstride), f32, x) if stats else None
+    # (rows of partial statistics: one per 128 output rows, a few more where the temporal window kernel's tiles do not
+    # divide the clip evenly -- callers pass partials.shape[0] on to bn_fwd, not geom.nblk)
+    partials = None
+    if stats:
+        nrows = H.igemm_stat_rows(geom.M, geom.out_cstride, geom.Kf, geom.g_fwd(), bna=x_bn is not None) if geom.groups == 1 else geom.nblk
+        partials = empty((nrows, 2, geom.out_cstride), f32, x)
     if geom.groups == 1:
         H.igemm(x, wf, y, geom.M, geom.out_cstride, geom.Kf, geom.g_fwd(), geom.Kf, geom.out_cstride,
                 b_rows=geom.Co, bias=bias, act=act, Cpre=pre, colstats=partials, ldstat=geom.out_cstride, bna=x_bn)

@@ -260,7 +260,7 @@ def run_plan(plan, cur, thw, B, training, save, first=False):
         y, partials = L.conv_fwd(inp, geom, wf, stats=training, x_bn=x_bn)
         fuse = (FUSE_BN_APPLY and next_conv is not None and relu and residual is None and
                 L.can_fuse_bn_apply(_geom(next_conv, B, geom.out_thw, False)))
-        z, sv = L.bn_fwd(y, partials, geom.nblk, geom.M, bn, relu=relu, residual=residual, eps=bn.eps,
+        z, sv = L.bn_fwd(y, partials, partials.shape[0] if partials is not None else geom.nblk, geom.M, bn, relu=relu, residual=residual, eps=bn.eps,
                          momentum=bn.momentum, update_running=training, apply=not fuse)
         rec = None
         if save:

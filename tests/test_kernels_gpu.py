@@ -1046,6 +1046,13 @@ def test_window_igemm_matches_gather_igemm(case):
     (144, 64, 1, 16, 56, 56),     # layer-1 frame size (196 tiles per clip)
     (144, 64, 2, 32, 8, 12),      # 32 frames (BASELINE configs[4] clips): 8 positions per tile
     (45, 64, 1, 32, 4, 14),       # stem at 32 frames
+    (144, 64, 2, 23, 10, 18),     # the reference's own 23 frames (round 4): 11 positions per tile, 3 dead tile rows, ragged last block
+    (45, 64, 1, 23, 50, 90),      # ... at its layer-1 frame size, stem channels
+    (64, 64, 3, 12, 5, 9),        # 12 frames (layer 2 of those clips): 21 positions per tile, 45 positions per frame
+    (144, 64, 4, 6, 7, 7),        # 6 frames, 42 positions per tile, 49 per frame: a full and a ragged tile per clip
+    (64, 144, 5, 3, 7, 12),       # 3 frames (layer 4): 85 positions per tile; 144 output columns (no statistics in that form)
+    (144, 64, 3, 31, 4, 4),       # 31 frames: 8 positions per tile, 8 dead rows
+    (64, 64, 8, 2, 9, 9),         # 2 frames: taps -1 and T both masked for every row
 ])
 def test_temporal_window_igemm_matches_gather_igemm(case):
     """Window kernel in its temporal form (tile = every frame of a block of positions, taps = +-block rows, frames -1
@@ -1446,6 +1453,10 @@ def test_sync_bn_two_ranks_in_one_process_match_the_global_batch():
     (144, 64, 1, 8, 8, 16),       # 8 frames
     (144, 64, 1, 16, 56, 56),     # layer-1 frame size
     (45, 64, 2, 16, 8, 16),       # the stem: 45 channels in one 48-channel chunk (pad channels: scale = shift = 0)
+    (144, 64, 2, 23, 10, 18),     # the reference's own 23 frames: ragged tiles (dead rows are activated too, and must stay out of
+                                  # the statistics)
+    (45, 64, 1, 23, 12, 20),      # ... the stem's channels
+    (144, 64, 1, 12, 9, 25),      # 12 frames: 21 positions per tile, 225 per frame
 ])
 def test_fused_batchnorm_apply_matches_the_separate_pass(case):
     """pp_igemm(a_bn_*) / pp_wgrad(x_bn_*): the temporal window kernel and the temporal sliding-window weight gradient apply

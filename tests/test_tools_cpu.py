@@ -91,3 +91,41 @@ def test_stream_timeline_splits_idle_time_by_cause(tmp_path):
     line = [l for l in text.splitlines() if l.startswith("| 1/0")][0].split("|")
     # trunk stream: busy 0.4 + 0.15 + 0.05 ms; gap 400..650 while stream 2 runs, gap 800..900 with nothing running
     assert abs(float(line[3]) - 0.60) < 1e-6 and abs(float(line[6]) - 0.25) < 1e-6 and abs(float(line[7]) - 0.15) < 1e-6
+
+
+def test_step_hbm_account_sums_every_family_with_the_gfx950_read_correction(tmp_path):
+    """tools/prof_step_traffic.py: FETCH_SIZE KiB x 2 and WRITE_SIZE KiB per dispatch, grouped by
+    kernel family, divided by the steps in the run; the total against the un-profiled step time."""
+    fd, wd = tmp_path / "fetch" / "run", tmp_path / "write" / "run"
+    fd.mkdir(parents=True)
+    wd.mkdir(parents=True)
+    rows, did = [], 1
+    for step in range(2):
+        for name, dur in ((WIN, 600.0), (BN, 400.0), ("bn_bwd_apply_kernel<true>(x)", 500.0), ("bertadam_kernel(pp_tensor_list)", 700.0)):
+            rows.append((did, 1, name, did * 1000.0, did * 1000.0 + dur))
+            did += 1
+    for d in (fd, wd):
+        _trace(str(d / "1_kernel_trace.csv"), rows)
+
+    def counters(path, counter, kib):
+        with open(path, "w", newline="") as f:
+            w = csv.writer(f, quoting=csv.QUOTE_ALL)
+            w.writerow(["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id",
+                        "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+                        "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+            for r in rows:      # two XCC partial rows per dispatch: the tool sums them
+                for part in range(2):
+                    w.writerow([r[0], r[0], 2, 1, 1, 1, 1, 1, r[2], 256, 0, 0, 64, 0, 32, counter, kib[r[2]] / 2, 0, 0])
+    counters(str(fd / "1_counter_collection.csv"), "FETCH_SIZE", {WIN: 500000, BN: 200000, rows[2][2]: 400000, rows[3][2]: 100000})
+    counters(str(wd / "1_counter_collection.csv"), "WRITE_SIZE", {WIN: 300000, BN: 200000, rows[2][2]: 200000, rows[3][2]: 50000})
+    md, js = str(tmp_path / "acct.md"), str(tmp_path / "acct.json")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_step_traffic.py"), str(tmp_path / "fetch"), str(tmp_path / "write"),
+                    "2", "40.0", md, js], check=True)
+    acct = json.load(open(js))
+    want_read = (500000 + 200000 + 400000 + 100000) * 1024 * 2
+    want_written = (300000 + 200000 + 200000 + 50000) * 1024
+    assert abs(acct["read_bytes"] - want_read) < 1 and abs(acct["written_bytes"] - want_written) < 1
+    assert abs(acct["step_bytes"] - (want_read + want_written)) < 1
+    assert abs(acct["families"]["BatchNorm apply"]["read"] - 200000 * 1024 * 2) < 1
+    assert abs(acct["hbm_floor_ms_at_6p3"] - (want_read + want_written) / 6.3e12 * 1e3) < 1e-9
+    assert "BatchNorm backward apply" in open(md).read()
