@@ -201,7 +201,8 @@ def igemm(A, Bt, Cout, M, N, K, g, ldb, ldc, *, b_rows=0, bias=None, act=ACT_NON
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append(("igemm", _MODE_NAMES[g.mode], M, N, K, nbatch, (g.kt, g.kh, g.kw), (g.st, g.sh, g.sw), g.cg))
     rc = []
-    _profiled(f"{_igemm_family(g)}<{_MODE_NAMES[g.mode]}> N={N} K={K}", 2.0 * M * N * K * nbatch,
+    # (a strided data gradient launched as one problem: a dx row only meets the taps of its parity class)
+    _profiled(f"{_igemm_family(g)}<{_MODE_NAMES[g.mode]}> N={N} K={K}", 2.0 * M * N * K * nbatch / (g.st * g.sh * g.sw if g.mode == CONV_DGRAD else 1),
               lambda: rc.append(call("pp_igemm", C.byref(d), _s())))
     return bnr is not None and rc[0] == 0
 

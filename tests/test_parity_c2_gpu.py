@@ -17,7 +17,8 @@ What bf16 activations cost, measured here with torch's own bf16 autocast of the 
     0.9-1.1 and the COSINE not below the yardstick's (0.46-0.53) minus 0.05; the well-conditioned parts (audio tower,
     projection) are asserted tightly;
   * the same for a CONDITIONED model (300 optimizer steps on structured clips, state loaded into the oracle): the
-    full-depth error leaves the ~1.0 regime (0.07-0.52) and is asserted with 1.2x headroom;
+    full-depth error leaves the ~1.0 regime (0.07-0.60) and is asserted against torch's own bf16 run (<= 1.15 x + 0.02), by norm
+    ratio and cosine, and with absolute bounds 1.4x above the larger of two measured runs (the training is not reproducible);
   * configs[1] at its true batch 64 (forward + loss) and configs[2] (frozen wav2vec2) at the real geometry.
 """
 import pytest

@@ -64,8 +64,14 @@ def join(trace_path, log_path):
 
 
 def flops(key):
-    _, _, M, N, K, nb, _, _ = key
-    return 2.0 * M * N * K * nb
+    """Algorithmic FLOPs of one launch.  A strided data gradient launched as ONE problem (the window kernel's S2D form, the
+    masked gather form) has M = rows of dx and K = every tap, but a dx row only meets the taps of its parity class:
+    st * sh * sw times fewer products than M * N * K."""
+    _, mode, M, N, K, nb, _, stride = key
+    f = 2.0 * M * N * K * nb
+    if mode == "conv_dgrad":
+        f /= stride[0] * stride[1] * stride[2]
+    return f
 
 
 def load_pmc(dirs):
