@@ -47,6 +47,9 @@ int pp_experimental_build(void);
  *   "win_s2d"      0/1 stride-(1,2,2) spatial data gradients as ONE window-kernel launch that reads dy once (default 1)
  *   "win_partial"  0/1 window kernels also for channel counts that are no multiple of 48 / 64 (464, 928): 64-channel chunks,
  *                      the last one partial (default 1)
+ *   "win_kpb"      1/2 K-steps per workgroup barrier in the 64-column window tiles (layer-1 data gradient, S2D): 2 (default)
+ *                      = a ring slot holds two K-steps, one wait + barrier + DMA issue per pair
+ *   "win_ragged"   0/1 temporal window form for frame counts / sizes that do not tile evenly (default 1)
  *   "wgrad_group_ring" 0/1 grouped weight gradients on the ring kernel's 128 x 256 tiles (default 0: measured slower)
  *   "deterministic" 0/1  bitwise-reproducible results: every sum that crosses workgroups is taken in a fixed order instead
  *                      of by fp32 atomics -- weight gradients through per-split slabs (pp_wgrad_desc.ws) and an ordered

@@ -27,6 +27,7 @@ extern int pp_opt_win_producers;
 extern int pp_opt_win_s2d;
 extern int pp_opt_win_partial;
 extern int pp_opt_win_ragged;
+extern int pp_opt_win_kpb;
 
 // Timing ablations for tools/probe/win_ablate.py (results are WRONG with any bit set; the shipped library has 0):
 // 1 weights only for a workgroup's first tile, 2 windows likewise, 4 no fragment reads / MFMAs, 8 no epilogue,
@@ -207,7 +208,7 @@ struct WinArgs {
 // PROD = four producer waves (8, 9: weights; 10, 11: windows) issue every LDS-DMA and do nothing else; the eight
 // multiplying waves issue none and never wait on vmcnt (wgrad_tw.hip measured why: a wave that multiplies is not at its
 // DMA instructions when the memory pipeline has room for them).  Twelve waves = three per SIMD = 168 registers each.
-template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false, bool STG = false, bool PROD = false, int HL = HALO, bool S2D = false>
+template <int WN, int CC, bool RES, int MT, int NBS, bool TW, bool BNR = false, bool BNA = false, bool STG = false, bool PROD = false, int HL = HALO, bool S2D = false, int KPB = 1>
 __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(const WinArgs p, const WinGeom g, const int nblk_n,
                                                           const int ntiles, const int xcd_remap, const int out_nt) {
   constexpr int BM = 16 * MT * NW;
@@ -228,11 +229,20 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   constexpr int HB = S2D ? 0 : HALO_, HA = HALO_;          // window rows before / after the tile's own
   constexpr int NCLS = S2D ? 4 : 1;                        // output parity classes (column-tile groups of the accumulators)
   static_assert(!S2D || (!TW && CC == 64 && !BNR && !BNA && !STG && MT == 2), "S2D: spatial form, 64-channel chunks");
+  // (three window buffers in the SPATIAL narrow form as well -- the window of the phase after next in flight -- were tried
+  // in round 4 for the layer-1 data gradient, whose phases of seven 16-MFMA K-steps are shorter than an HBM round trip:
+  // 630-636 us against 613-623, i.e. its parked waves do not wait for windows; profiles/r04_probe_gemm_w3.log)
   constexpr int NWIN = (TW && WN <= 4) ? 3 : 2;
   constexpr int D = NWIN - 1;                                 // phases of window look-ahead
   constexpr int WROWS = BM + HB + HA;
   constexpr int BN = 16 * WN;
   constexpr int B_BYTES = BN * 128;
+  // KPB = K-steps per barrier (round 4).  With 64 output columns a K-step is 16 MFMAs per wave -- 256 clocks of matrix work
+  // between two workgroup barriers, each of which also exposes the LDS latency of the K-step's first fragments.  KPB = 2
+  // makes a ring slot hold TWO K-steps (a "group"): one wait + barrier + DMA issue per group, and the second K-step's
+  // fragment reads fly under the first one's MFMAs.  The ring logic is unchanged with "K-step" read as "group".
+  constexpr int B_SLOT = KPB * B_BYTES;
+  static_assert(KPB == 1 || (KPB == 2 && !TW && !STG && !BNR && !BNA), "KPB = 2: spatial form, plain epilogue");
   constexpr int XS = CC == 64 ? 128 : CC * 2 + 16;            // window row stride; 128-byte rows are XOR-swizzled
   constexpr int WIN_BYTES = WROWS * XS;
   constexpr int WPIECES = WIN_BYTES / 1024;
@@ -272,13 +282,13 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   static_assert(STG_BYTES <= WIN_BYTES && STAT_BYTES <= B_BYTES, "the epilogue stages in a window buffer / weight slot");
   static_assert(!RW || WN > 4 || STG_BYTES + STAT_BYTES <= WIN_BYTES, "resident weights: the statistics stage behind the output");
   constexpr int BNA_CH = 160;                                 // channels of the BatchNorm parameter table (BNA)
-  constexpr int SMEM = NWIN * WIN_BYTES + NBS * B_BYTES + 256 + 64 + (BNA ? 2 * BNA_CH * 4 : 0);
+  constexpr int SMEM = NWIN * WIN_BYTES + NBS * B_SLOT + 256 + 64 + (BNA ? 2 * BNA_CH * 4 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static_assert(!BNA || (TW && CC == 48), "BNA: temporal form, 48-channel chunks");
   static_assert(!STG || (!TW && NBS == 3 && !BNA), "staggered halves: spatial form with a three-slot weight ring");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];   // one LDS object (see igemm.hip)
   unsigned char* const bring = smem + NWIN * WIN_BYTES;
-  unsigned char* const zrow = smem + NWIN * WIN_BYTES + NBS * B_BYTES;    // 256 zero bytes
+  unsigned char* const zrow = smem + NWIN * WIN_BYTES + NBS * B_SLOT;    // 256 zero bytes
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -475,6 +485,18 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 #pragma unroll
     for (int i = 0; i < NBI; ++i)
       if (i < NBI - 1 || b_last) lds_dma16(rsB, dst + 8 * NWB * i * 128, bvoff[i] + koff);
+  };
+
+  // all K-steps of group `gi` (KPB consecutive K-steps, the last group of a chunk may be short) into ring slot `slot`;
+  // returns the number of DMA instructions this wave issued
+  constexpr int NKC_ = (NTAP * CC + BK - 1) / BK;
+  constexpr int NG = (NKC_ + KPB - 1) / KPB;                 // groups per chunk
+  auto dma_group = [&](unsigned char* slot, const int chunk_, const int gi) __attribute__((always_inline)) -> int {
+    int n = 0;
+#pragma unroll
+    for (int t = 0; t < KPB; ++t)
+      if (gi * KPB + t < NKC_) { dma_weights(slot + t * B_BYTES, chunk_, gi * KPB + t); n += nB; }
+    return n;
   };
 
   // ---- per-tile state -------------------------------------------------------------------------------------------
@@ -951,7 +973,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         for (int j = 0; j < NKC; ++j) dma_weights(bring + (c * NKC + j) * B_BYTES, c, j);
     } else {
 #pragma unroll
-      for (int a = 0; a < LA; ++a) dma_weights(bring + a * B_BYTES, 0, a);      // (NKC >= 6 > LA)
+      for (int a = 0; a < LA; ++a) dma_group(bring + a * B_SLOT, 0, a);      // (NG >= 4 > LA)
     }
   }
   if (DMA && win_wave) {        // (a DUAL producer: after its share of the resident weights; the first wait drains both)
@@ -1012,12 +1034,18 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         // weight waves, three slots: everything but the batch of the previous iteration (the weights of step s + 1) must
         // have landed; two slots: that batch IS the weights of this step.  Window waves: this phase's window, issued at
         // the start of the previous phase, must have landed when the phase starts; nothing to wait for inside a phase.
+        const bool gfirst = j % KPB == 0;     // first K-step of its group: the group's wait, barrier and DMA issue (KPB)
         auto sync = [&]() __attribute__((always_inline)) {
+        if (!gfirst) return;
         if (!DMA) {
         } else if (win_wave) {
           // this phase's window has landed once only the younger one (D = 2) is still in flight; a tile's first phase
           // also waits for the epilogue's stores, which sit between them in the counter
-          if (j == 0) wait_vmcnt_dyn((drain || D == 1) ? 0 : last_win);
+          // (producer waves issue no stores: their look-ahead survives the tile boundary)
+#ifndef PP_WIN_PROD_DRAIN
+#define PP_WIN_PROD_DRAIN 0
+#endif
+          if (j == 0) wait_vmcnt_dyn(((drain && (!PROD || PP_WIN_PROD_DRAIN)) || D == 1) ? 0 : last_win);
         } else if (wgt_wave) {
           wait_vmcnt_dyn((drain || NBS == 2 || RW || STG) ? 0 : last_batch);
         }
@@ -1077,6 +1105,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         };
         PP_STAMP(1)
         auto issue_dmas = [&](const int pos) __attribute__((always_inline)) {
+          if (!gfirst) return;
           if (pos >= 0 && pos != (win_wave ? PP_WIN_WPOS : (STG ? 0 : 1))) return;   // (STG: the weights have ONE step to land: issue first)
           if (!DMA) {
           } else if (win_wave) {
@@ -1096,30 +1125,28 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
             } else if (nvalid) {
 #pragma unroll
               for (int k = 0; k < NWP; ++k)
-                if (k >= j * PPK && k < (j + 1) * PPK) dma_window_piece(k, nwin, nbase);
+                if (k >= j * PPK && k < (j + KPB) * PPK) dma_window_piece(k, nwin, nbase);
             }
           } else if (wgt_wave && !RW) {
-            // the K-step LA ahead: (chunk, j + LA), or the first ones of the next chunk
-            const int j2 = j + LA < NKC ? j + LA : j + LA - NKC;
-            const int c2 = j + LA < NKC ? chunk : chunk + 1;
+            // the group LA ahead: (chunk, j / KPB + LA), or the first ones of the next chunk
+            const int g2 = j / KPB + LA < NG ? j / KPB + LA : j / KPB + LA - NG;
+            const int c2 = j / KPB + LA < NG ? chunk : chunk + 1;
             last_batch = 0;
-            if (c2 < nchunk) {
-              dma_weights(bring + slot_ahead(bsl) * B_BYTES, c2, j2);
-              last_batch = nB;
-            }
+            if (c2 < nchunk) last_batch = dma_group(bring + slot_ahead(bsl) * B_SLOT, c2, g2);
           }
         };
         PP_STAMP(2)
-        compute(comp_c, j, win, bring + (RW ? chunk * NKC + j : bsl) * B_BYTES, issue_dmas, sync, STG && win_wave && j > 0);
+        compute(comp_c, j, win, RW ? bring + (chunk * NKC + j) * B_BYTES : bring + bsl * B_SLOT + (j % KPB) * B_BYTES, issue_dmas, sync,
+                STG && win_wave && j > 0);
         PP_STAMP(3)
-        bsl = next_slot(bsl);
+        if (j % KPB == KPB - 1 || j == NKC - 1) bsl = next_slot(bsl);
       }
       wsel = wsel + 1 == NWIN ? 0 : wsel + 1;
     }
     const int mb_done = mb, nb_done = nb;
     unsigned char* const ebuf = smem + (wsel == 0 ? NWIN - 1 : wsel - 1) * WIN_BYTES;   // the window just consumed stages the output
     unsigned char* const sbuf = RW ? ebuf + STG_BYTES                                // ... the weight slot just consumed the statistics
-                                   : bring + (bsl == 0 ? NBS - 1 : bsl - 1) * B_BYTES;
+                                   : bring + (bsl == 0 ? NBS - 1 : bsl - 1) * B_SLOT;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                               // every wave is done reading it
     if (next_tile >= 0) {                                       // the next tile's first weight steps fly under the epilogue
@@ -1130,7 +1157,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         int sl = bsl;
 #pragma unroll
         for (int a = 0; a < LA; ++a) {
-          dma_weights(bring + sl * B_BYTES, 0, a);
+          dma_group(bring + sl * B_SLOT, 0, a);
           sl = next_slot(sl);
         }
       }
@@ -1169,7 +1196,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
 template <int WN, int CC, int MT, bool TW>
 constexpr bool bnr_built() { return TW ? (CC == 64 && WN == 4) : (WN == 4 || WN == 8); }   // (MT x NIT <= 8 chunks of y per lane)
 
-template <int WN, int CC, int MT, int NBS, bool TW = false, int HL = HALO, bool S2D = false>
+template <int WN, int CC, int MT, int NBS, bool TW = false, int HL = HALO, bool S2D = false, int KPB = 1>
 int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   constexpr int BN = 16 * WN, BM = 16 * MT * NW;
   const pp_gather& gg = d.g;
@@ -1208,17 +1235,18 @@ int launch_win(const pp_igemm_desc& d, hipStream_t s) {
   dim3 grid((unsigned)gx, 1, 1), block(NT);
   if constexpr (S2D) {
     if (bna) { pp_set_error("pp_igemm: fused BatchNorm apply is built for the temporal window kernel only"); return PP_ERR_INVALID; }
-    if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, false, HL, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
-    else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, false, HL, true>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+    if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, false, HL, true, KPB>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+    else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, false, HL, true, KPB>), grid, block, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
     PP_LAUNCH_CHECK();
     return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
-  } else if constexpr (!TW && HL != HALO) {
-    // frames wider than 63 (HL = 96 rows of halo): the producer form only -- no BatchNorm-backward sums in the epilogue
-    // (the caller runs pp_bn_bwd_reduce: PP_BNR_SKIPPED), no staggered / lockstep variants
+  } else if constexpr (!TW && (HL != HALO || KPB != 1)) {
+    // frames wider than 63 (HL = 96 rows of halo), and the two-K-steps-per-barrier form (KPB = 2) of the 64-column tiles:
+    // the producer form only -- no BatchNorm-backward sums in the epilogue (the caller runs pp_bn_bwd_reduce:
+    // PP_BNR_SKIPPED), no staggered / lockstep variants
     if (bna) { pp_set_error("pp_igemm: fused BatchNorm apply is built for the temporal window kernel only"); return PP_ERR_INVALID; }
     dim3 pblock(NT + 256);
-    if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, true, HL>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
-    else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, true, HL>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+    if (d.residual) hipLaunchKernelGGL((igemm_win_kernel<WN, CC, true, MT, NBS, TW, false, false, false, true, HL, false, KPB>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
+    else hipLaunchKernelGGL((igemm_win_kernel<WN, CC, false, MT, NBS, TW, false, false, false, true, HL, false, KPB>), grid, pblock, 0, s, a, g, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, pp_opt_win_out_nt);
     PP_LAUNCH_CHECK();
     return d.bnr_partials ? PP_BNR_SKIPPED : PP_OK;
   } else {
@@ -1353,7 +1381,7 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
                       g.ph == 1 && g.pw == 1 && g.Gt == g.Rt && g.Gh == (g.Rh + 1) / 2 && g.Gw == (g.Rw + 1) / 2 && g.Gw + 1 <= HALO &&
                       d.K == 9 * g.cg && g.cg % 8 == 0 && g.cstride >= ((g.cg + 63) & ~63) - 56 &&
                       (long long)d.M * 2 < 0x7f000000LL && (long long)d.M / 2 * g.cstride < 0x7f000000LL && (!d.residual || d.ldr % 8 == 0);
-  if (s2d_ok) return launch_win<4, 64, 2, 3, false, HALO, true>(d, s);
+  if (s2d_ok) return pp_opt_win_kpb == 2 ? launch_win<4, 64, 2, 3, false, HALO, true, 2>(d, s) : launch_win<4, 64, 2, 3, false, HALO, true>(d, s);
   constexpr int HALO_WIDE = 96;
   const bool shape_ok = conv && d.nbatch == 1 && !d.c_fp32 && !d.bias && d.act == PP_ACT_NONE && !d.Cpre && !d.omap && d.drop_p == 0.f &&
                         g.kt == 1 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 &&
@@ -1372,7 +1400,7 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
       if (n16 <= 4) return launch_win<4, 64, 2, 3, false, HALO_WIDE>(d, s);
       return c9 <= c8 ? launch_win<9, 64, 2, 2, false, HALO_WIDE>(d, s) : launch_win<8, 64, 2, 2, false, HALO_WIDE>(d, s);
     }
-    if (n16 <= 4) return launch_win<4, 48, 2, 3, false, HALO_WIDE>(d, s);
+    if (n16 <= 4) return pp_opt_win_kpb == 2 ? launch_win<4, 48, 2, 3, false, HALO_WIDE, false, 2>(d, s) : launch_win<4, 48, 2, 3, false, HALO_WIDE>(d, s);
     return c9 <= c8 ? launch_win<9, 48, 2, 2, false, HALO_WIDE>(d, s) : launch_win<8, 48, 2, 2, false, HALO_WIDE>(d, s);
   }
   // tile widths: 64 columns (narrow outputs) or 128 / 144 (whichever pads N less)
@@ -1385,6 +1413,8 @@ int pp_igemm_win_try(const pp_igemm_desc& d, hipStream_t s) {
     // narrow output from 48-channel chunks (the layer-1 data gradient): 512-row tiles, four row tiles per wave, when
     // there are enough rows to give every CU a few of them and no statistics are asked for
     if (pp_opt_win_tall && !d.colstats && (pp_opt_win_tall == 2 || (long long)d.M >= 512LL * 256 * 2)) return launch_win<4, 48, 4, 2>(d, s);   // (2 = forced: tests)
+    // (two K-steps per barrier where the producer form runs and nothing is asked of the epilogue: the layer-1 data gradient)
+    if (pp_opt_win_kpb == 2 && pp_opt_win_producers && !d.colstats && !d.bnr_partials) return launch_win<4, 48, 2, 3, false, HALO, false, 2>(d, s);
     return launch_win<4, 48, 2, 3>(d, s);
   }
   const int c8 = ((n16 + 7) / 8) * 8, c9 = ((n16 + 8) / 9) * 9;
