@@ -90,6 +90,7 @@ def set_switch(name, on):
         H.set_option("wgrad_flat", 1 if on else 0)
         H.set_option("win_tall", 0 if on else 1)
         H.set_option("win_partial", 1 if on else 0)
+        H.set_option("win_kpb", 2 if on else 1)
     elif name == "win_stagger":
         from peppa_amd import hip as H
         H.set_option("win_stagger", 1 if on else 0)
