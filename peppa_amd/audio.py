@@ -198,16 +198,17 @@ def _fe_forward(fe, wave, save):
     H.conv0_apply(wave, B, Lw, T0, t.w0, t.stats, blk0.layer_norm.weight, blk0.layer_norm.bias, blk0.layer_norm.eps, cur)
     t.wave, t.layers = wave, []
     Tcur = T0
-    for blk in fe.conv_layers[1:]:
-        k, s = blk.conv.kernel_size[0], blk.conv.stride[0]
-        geom = L.ConvGeom(B, (Tcur, 1, 1), 512, 512, (k, 1, 1), (s, 1, 1), (0, 0, 0))
-        wf, wd = L.prep_conv_weights(blk.conv.weight, geom, need_dgrad=save)
-        pre = L.empty((geom.M, 512), act16(), wave) if save else None
-        y, _ = L.conv_fwd(cur, geom, wf, act=H.ACT_GELU, pre=pre)
-        r = _Rec()
-        r.blk, r.geom, r.wd, r.x, r.pre = blk, geom, wd, cur, pre
-        t.layers.append(r)
-        cur, Tcur = y, geom.To
+    with L.PrepPlan(("wav2vec2-fe", id(fe), (B, Lw), bool(save))):       # the six convolutions' operands in one launch
+        for blk in fe.conv_layers[1:]:
+            k, s = blk.conv.kernel_size[0], blk.conv.stride[0]
+            geom = L.ConvGeom(B, (Tcur, 1, 1), 512, 512, (k, 1, 1), (s, 1, 1), (0, 0, 0))
+            wf, wd = L.prep_conv_weights(blk.conv.weight, geom, need_dgrad=save)
+            pre = L.empty((geom.M, 512), act16(), wave) if save else None
+            y, _ = L.conv_fwd(cur, geom, wf, act=H.ACT_GELU, pre=pre)
+            r = _Rec()
+            r.blk, r.geom, r.wd, r.x, r.pre = blk, geom, wd, cur, pre
+            t.layers.append(r)
+            cur, Tcur = y, geom.To
     t.T = Tcur
     return cur, Tcur, t
 

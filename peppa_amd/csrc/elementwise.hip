@@ -143,6 +143,25 @@ __global__ void prep_conv_kernel(const float* __restrict__ w, int Co, int Ci, in
     out[i] = f2h(v);
   }
 }
+// the same for a device table of weights in one launch (blockIdx.y = weight): a tower's ~40 convolutions x 2 layouts are
+// 4-8 us launches each on its critical stream
+struct PrepItem { const float* w; h16raw* out; long long Co, Ci, taps, rows_out, cg, transpose_io, flip; float scale; int pad; };
+__global__ __launch_bounds__(256) void prep_conv_multi_kernel(const PrepItem* __restrict__ items) {
+  const PrepItem it = items[blockIdx.y];
+  const int Co = (int)it.Co, Ci = (int)it.Ci, taps = (int)it.taps, cg = (int)it.cg;
+  const long long n = it.rows_out * it.taps * it.cg;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cg);
+    const long long t2 = i / cg;
+    int tap = (int)(t2 % taps);
+    const int row = (int)(t2 / taps);
+    if (it.flip) tap = taps - 1 - tap;
+    const int co = it.transpose_io ? c : row, ci = it.transpose_io ? row : c;
+    float v = 0.f;
+    if (co < Co && ci < Ci) v = it.w[((long long)co * Ci + ci) * taps + tap] * it.scale;
+    it.out[i] = f2h(v);
+  }
+}
 __global__ void unprep_conv_kernel(const float* __restrict__ g, int Co, int Ci, int taps, int cg, float* __restrict__ dw) {
   GSTRIDE(i, (long long)Co * Ci * taps) {
     const int tap = (int)(i % taps);
@@ -322,6 +341,13 @@ extern "C" int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, voi
   PP_CHECK_ARG(transpose_io ? (rows_out >= Ci && cg >= Co) : (rows_out >= Co && cg >= Ci), "pp_prep_conv_weight: pad too small");
   hipLaunchKernelGGL(prep_conv_kernel, dim3(sgrid((long long)rows_out * taps * cg)), dim3(256), 0, S_, w, Co, Ci, taps,
                      (h16raw*)out, rows_out, cg, transpose_io, flip, scale);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_prep_conv_weight_multi(const void* items, int n, int blocks_per_item, pp_stream_t s) {
+  PP_CHECK_ARG(items && n > 0 && n <= 65535 && blocks_per_item > 0, "pp_prep_conv_weight_multi: bad arguments");
+  static_assert(sizeof(PrepItem) == 80, "pp_prep_item layout (9 x 8 bytes, float scale, 4 bytes of padding)");
+  hipLaunchKernelGGL(prep_conv_multi_kernel, dim3(blocks_per_item, n), dim3(256), 0, S_, (const PrepItem*)items);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

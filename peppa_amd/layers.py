@@ -5,6 +5,8 @@ the encoders (video.py / audio.py) chain them inside one autograd.Function per e
 activation buffers, weight operand layouts and streams are managed by hand instead of by a
 tracing compiler.  No torch arithmetic happens here: torch only allocates.
 """
+import weakref
+
 import torch
 
 from . import hip as H
@@ -132,6 +134,7 @@ WEIGHT_EPOCH = 0
 _OPERANDS = {}
 _OPERANDS_EPOCH = [0]
 CACHE_OPERANDS = False
+PREP_PLAN = True         # one launch for a tower's convolution operands (PrepPlan); False: two launches per convolution
 
 
 def weights_changed():
@@ -140,20 +143,83 @@ def weights_changed():
     WEIGHT_EPOCH += 1
 
 
+def _operand_slot(key, params):
+    return (key, H.precision()) + tuple(p.data_ptr() for p in params), tuple(p._version for p in params)
+
+
 def cached_operands(key, params, build):
-    """build() -> operands of `params` (weights), memoised until one of them changes; key names the layout."""
+    """build() -> operands of `params` (weights), memoised until one of them changes; key names the layout.  One entry per
+    (layout, weight): a new version of the weight replaces it."""
     if not CACHE_OPERANDS:
         return build()
     if _OPERANDS_EPOCH[0] != WEIGHT_EPOCH:
         _OPERANDS.clear()
         _OPERANDS_EPOCH[0] = WEIGHT_EPOCH
-    full = (key, H.precision()) + tuple((p.data_ptr(), p._version) for p in params)
-    hit = _OPERANDS.get(full)
-    if hit is None:
+    slot, versions = _operand_slot(key, params)
+    hit = _OPERANDS.get(slot)
+    if hit is None or hit[0] != versions:
         if len(_OPERANDS) > 4096:
             _OPERANDS.clear()
-        hit = _OPERANDS[full] = build()
-    return hit
+        hit = _OPERANDS[slot] = (versions, build())
+    return hit[1]
+
+
+def _conv_operand_key(geom, need_dgrad):
+    return ("conv", geom.Co, geom.Cig, geom.taps, geom.cg_in, geom.cg_out, geom.groups, geom.Ci, bool(need_dgrad))
+
+
+class PrepPlan:
+    """The convolution weight operands of a whole tower in ONE launch (pp_prep_conv_weight_multi) instead of two 4-8 us
+    launches per convolution on the tower's critical stream.  `with PrepPlan(key):` around a tower's forward pass: the first
+    pass records which (weight, geometry) pairs prep_conv_weights is asked for; later passes build all of them on entry
+    (those the operand cache does not already hold) and hand them out as the layers ask.  A recorded pair that is not asked
+    for again costs one wasted conversion; a pair that was not recorded is built on its own as before."""
+    _plans = {}
+    _active = []
+
+    def __init__(self, key):
+        self.key, self.seen, self.ready, self._keep = key, [], {}, None
+
+    def __enter__(self):
+        if PREP_PLAN:
+            self._build(PrepPlan._plans.get(self.key, ()))
+        PrepPlan._active.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        PrepPlan._active.pop()
+        if exc[0] is None:
+            PrepPlan._plans[self.key] = self.seen
+        self.ready = {}
+        return False
+
+    def _build(self, entries):
+        jobs = []
+        for wref, geom, need_dgrad in entries:
+            w = wref()
+            if w is None or not w.is_cuda or not w.is_contiguous():
+                continue
+            key = _conv_operand_key(geom, need_dgrad)
+            if (w.data_ptr(), key) in self.ready:
+                continue
+            if CACHE_OPERANDS and _OPERANDS_EPOCH[0] == WEIGHT_EPOCH:
+                slot, versions = _operand_slot(key, (w,))
+                hit = _OPERANDS.get(slot)
+                if hit is not None and hit[0] == versions:
+                    continue
+            wf = empty((geom.Co, geom.taps, geom.cg_in), act16(), w)
+            jobs.append((w, wf, geom.Co, geom.Cig, geom.taps, geom.Co, geom.cg_in, False))
+            wd = None
+            if need_dgrad:
+                wd = empty((geom.Ci, geom.taps, geom.cg_out), act16(), w)
+                jobs.append((w, wd, geom.Co, geom.Ci, geom.taps, geom.Ci, geom.cg_out, True))
+            self.ready[(w.data_ptr(), key)] = (wf, wd)
+        if jobs:
+            self._keep = H.prep_conv_weight_multi(jobs, jobs[0][0].device)
+
+    def take(self, w, geom, need_dgrad):
+        self.seen.append((weakref.ref(w), geom, need_dgrad))
+        return self.ready.pop((w.data_ptr(), _conv_operand_key(geom, need_dgrad)), None)
 
 
 def prep_conv_weights(w, geom, need_dgrad=True):
@@ -162,8 +228,11 @@ def prep_conv_weights(w, geom, need_dgrad=True):
         assert not need_dgrad, "a paired-pixel stem is a first layer: no data gradient"
         key = ("conv-pairs", geom.Co, geom.k, geom.pairs)
         return cached_operands(key, (w,), lambda: (_prep_conv_weights_pairs(w, geom), None))
-    key = ("conv", geom.Co, geom.Cig, geom.taps, geom.cg_in, geom.cg_out, geom.groups, geom.Ci, bool(need_dgrad))
-    return cached_operands(key, (w,), lambda: _prep_conv_weights(w, geom, need_dgrad))
+    if geom.groups == 1 and PrepPlan._active:
+        ready = PrepPlan._active[-1].take(w, geom, need_dgrad)
+        if ready is not None:
+            return cached_operands(_conv_operand_key(geom, need_dgrad), (w,), lambda: ready)
+    return cached_operands(_conv_operand_key(geom, need_dgrad), (w,), lambda: _prep_conv_weights(w, geom, need_dgrad))
 
 
 def _prep_conv_weights_pairs(w, geom):

@@ -236,7 +236,8 @@ def trunk_forward(net, x, norm_kind, training, save):
     """x fp32 [B][3][T][H][W] (or uint8 [B][T][H][W][3]) -> (z 16-bit [B*T'*H'*W'][512], (T',H',W'), tape)."""
     plan = net.units()
     cur, (T, Hh, W), B = normalized_input(x, norm_kind, plan[0][1] if plan and plan[0][0] == "unit" else None)
-    return run_plan(plan, cur, (T, Hh, W), B, training, save, first=True)
+    with L.PrepPlan(("video", id(net), tuple(x.shape), bool(save))):      # every convolution's operands in one launch
+        return run_plan(plan, cur, (T, Hh, W), B, training, save, first=True)
 
 
 FUSE_BN_APPLY = True   # A/B switch (tools/ab_step.py fuse_bn_apply): see run_plan

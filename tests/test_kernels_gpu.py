@@ -1543,3 +1543,38 @@ def test_paired_pixel_stem_matches_conv3d(case):
     close(dw, wr.grad, name="paired stem weight gradient vs conv3d")
     sc = dw8.abs().max().item()
     assert (dw - dw8).abs().max().item() <= 2e-5 * sc + 1e-6
+
+
+def test_one_launch_weight_preparation_matches_the_per_convolution_launches():
+    """layers.PrepPlan (pp_prep_conv_weight_multi): a tower's convolution operands built in one launch on the second and
+    later passes are bit-identical to pp_prep_conv_weight's, also after the weights have moved, for both layouts, channel
+    counts that are no multiple of 8 / 64 (45, 230, 460) and convolutions without a data gradient."""
+    torch.manual_seed(3)
+    shapes = [(45, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 8, 8), True), (64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 8, 8), True),
+              (64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), (4, 8, 8), True), (230, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), (4, 4, 4), True),
+              (256, 460, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 4), True), (512, 512, (3, 1, 1), (2, 1, 1), (0, 0, 0), (33, 1, 1), False)]
+    ws = [torch.randn(Co, Ci, *k, device="cuda") * 0.1 for (Ci, Co, k, _, _, _, _) in shapes]
+    geoms = [L.ConvGeom(2, thw, Ci, Co, k, st, pd) for (Ci, Co, k, st, pd, thw, _) in shapes]
+
+    def one_pass():
+        with L.PrepPlan(("test-prep-plan",)) as plan:
+            got = [L.prep_conv_weights(w, g, need_dgrad=sh[6]) for w, g, sh in zip(ws, geoms, shapes)]
+            return got, len(plan.ready)
+
+    L.PrepPlan._plans.pop(("test-prep-plan",), None)
+    first, left = one_pass()                       # records; every operand built on its own
+    assert left == 0
+    for it in range(2):
+        for w in ws:
+            w.mul_(1.5).add_(0.01)                 # the optimizer moves the masters
+        got, left = one_pass()                     # built on entry, in one launch
+        assert left == 0, "every prepared operand was asked for"
+        prev, L.PREP_PLAN = L.PREP_PLAN, False
+        try:
+            ref, _ = one_pass()
+        finally:
+            L.PREP_PLAN = prev
+        for (wf, wd), (rf, rd), sh in zip(got, ref, shapes):
+            assert torch.equal(wf, rf)
+            assert (wd is None and rd is None) if not sh[6] else torch.equal(wd, rd)
+    L.PrepPlan._plans.pop(("test-prep-plan",), None)

@@ -17,7 +17,7 @@ T_IN=$(ls $D/prof/instep/*/*_kernel_trace.csv | head -1); T_AL=$(ls $D/prof/alon
 python tools/prof_shapes.py $T_IN $D/prof/instep_launch.json $D/${R}_shapes.md "$TITLE: every matrix-core launch of the hparams_base step by SHAPE (B = 64, bf16)" --alone $T_AL $D/prof/alone_launch.json --pmc $D/prof/pmc_sq --pmc-log $D/prof/pmc_launch.json
 python tools/prof_traffic.py $D/prof/pmc_fetch $D/prof/pmc_write $D/prof/traffic_launch.json $D/${R}_pmc_traffic.md $D/${R}_traffic.json
 python tools/prof_step_traffic.py $D/prof/pmc_fetch $D/prof/pmc_write 3 $STEP_MS $D/${R}_step_hbm_account.md $D/${R}_step_hbm_account.json
-python tools/prof_families.py $T_IN $T_AL 9 $D/${R}_families_alone_vs_instep.md "$TITLE: kernel families alone vs in-step (hparams_base, B=64, bf16; 3 warm-up + 6 timed steps, all 9 counted)"
+python tools/prof_families.py $T_IN $T_AL 9 $D/${R}_families_alone_vs_instep.md "$TITLE: kernel families alone vs in-step (hparams_base, B=64, bf16; 3 warm-up + 6 timed steps, the 6 timed ones counted)" 3
 python tools/prof_timeline.py $T_IN $D/${R}_rocprof_stream_timeline.md "$TITLE: per-stream timeline of the step UNDER rocprofv3 (the profiler adds ~15 us per launch; see ${R}_step_timeline.md for the undistorted phases)" --steps 4
 python tools/step_timeline.py --out $D/${R}_step_timeline.md > $D/step_timeline.log 2>&1
 python tools/step_timeline.py --video-only --out $D/${R}_step_timeline_video_only.md > $D/step_timeline_vo.log 2>&1
