@@ -694,6 +694,15 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
   };
   auto epilogue = [&](const int mb_e, const int nb_e, unsigned char* const ebuf, unsigned char* const sbuf, const int cls) __attribute__((always_inline)) {
     const int m_wave = mb_e * BM + wave * (16 * MT);
+    // temporal form: the rows' global indices (tw_row: two exact divisions each since the ragged form of round 4) are computed
+    // HERE.  They depend on the tile and the lane only, so the compiler computed all MT x NIT of them before the K loop and,
+    // with 168 registers per wave in the producer form, spilled them: +11 exposed scratch loads per tile, 315 -> 383 us on
+    // the 144-column layer-1 data gradient (profiles/r04_probe_tw_regress.log).  Two opaque copies keep them behind the loop.
+    int mb_t = mb_e, lr0 = wave * (16 * MT);
+    if (TW) {
+      asm volatile("" : "+s"(mb_t));
+      asm volatile("" : "+v"(lr0));
+    }
     const int ca = cls * WN;                          // this class's column tiles of the accumulators (S2D; else 0)
     const int m_lim = S2D ? g.Mout : g.M;
     unsigned char* stg = ebuf + wave * 16 * STG_STRIDE;
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         const int row = BNR ? b_rsub + RPI * it : cid / CPR;
         const int ch = BNR ? b_ch : cid % CPR;
         const bool live = BNR ? (b_rsub < RPI && row < 16) : cid < 32 * WN;
-        int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
+        int m = TW ? tw_row(mb_t, lr0 + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
         if (S2D) { m = s2d_row(m, cls); if (m < 0) m = m_lim; }
         const int col = nb_e * BN + ch * 8;
         rpre[mt * NIT + it] = (live && m < m_lim && col < ncols_store) ? *(const uint4*)(p.residual + (long long)m * p.ldr + col) : make_uint4(0, 0, 0, 0);
@@ -741,7 +750,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         for (int it = 0; it < NIT; ++it) {
           const int row = b_rsub + RPI * it;
           const bool live = cok && row < 16;
-          const int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
+          const int m = TW ? tw_row(mb_t, lr0 + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
           ypre[mt * NIT + it] = (live && m < g.M) ? *(const uint4*)(p.bnr_y + (long long)m * p.ldc + c0) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(PROD ? NT + 256 : NT, 1) void igemm_win_kernel(cons
         const int row = BNR ? b_rsub + RPI * it : cid / CPR;
         const int ch = BNR ? b_ch : cid % CPR;
         const bool live = BNR ? (b_rsub < RPI && row < 16) : cid < 32 * WN;
-        int m = TW ? tw_row(mb_e, wave * (16 * MT) + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
+        int m = TW ? tw_row(mb_t, lr0 + mt * 16 + (live ? row : 0)) : m_wave + mt * 16 + row;
         if (S2D) { m = s2d_row(m, cls); if (m < 0) m = m_lim; }
         const int col = nb_e * BN + ch * 8;
         if (live && m < m_lim && col < ncols_store) {

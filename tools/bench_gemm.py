@@ -28,10 +28,10 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e-3
 
 
-def conv_case(name, Ci, Co, k, s, p, thw):
+def conv_case(name, Ci, Co, k, s, p, thw, in_cstride=None, out_cstride=None):
     if case_filter and case_filter not in name:
         return
-    geom = L.ConvGeom(B, thw, Ci, Co, k, s, p)
+    geom = L.ConvGeom(B, thw, Ci, Co, k, s, p, in_cstride=in_cstride, out_cstride=out_cstride)
     x = torch.randn(geom.Min, geom.in_cstride, device=dev).to(torch.bfloat16)
     dy = torch.randn(geom.M, geom.out_cstride, device=dev).to(torch.bfloat16)
     w = torch.randn(Co, Ci, *k, device=dev) * 0.05
@@ -84,6 +84,13 @@ conv_case("l3 temporal 576->256", 576, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), g3)
 conv_case("l4 spatial 512->1152", 512, 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1), g4)
 conv_case("l4 temporal 1152->512", 1152, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), g4)
 conv_case("audio conv1 k3s2 T=7359", 512, 512, (3, 1, 1), (2, 1, 1), (0, 0, 0), (7359, 1, 1))
+# the same with rows of 576 / 640 instead of 512 channels (1152 / 1280 B instead of a power of two: HBM channel spread)
+conv_case("audio conv1 rows of 576", 512, 512, (3, 1, 1), (2, 1, 1), (0, 0, 0), (7359, 1, 1), in_cstride=576, out_cstride=576)
+conv_case("audio conv1 rows of 520", 512, 512, (3, 1, 1), (2, 1, 1), (0, 0, 0), (7359, 1, 1), in_cstride=520, out_cstride=520)
+conv_case("audio conv2 k3s2 T=3679", 512, 512, (3, 1, 1), (2, 1, 1), (0, 0, 0), (3679, 1, 1))
+conv_case("audio conv2 rows of 576", 512, 512, (3, 1, 1), (2, 1, 1), (0, 0, 0), (3679, 1, 1), in_cstride=576, out_cstride=576)
+conv_case("audio conv5 k2s2 T=459", 512, 512, (2, 1, 1), (2, 1, 1), (0, 0, 0), (459, 1, 1))
+conv_case("audio conv5 rows of 576", 512, 512, (2, 1, 1), (2, 1, 1), (0, 0, 0), (459, 1, 1), in_cstride=576, out_cstride=576)
 M = B * int(os.environ.get("AUDIO_T", "114"))
 dense_case("qkv 768->2304", M, 2304, 768)
 dense_case("out 768->768", M, 768, 768)
