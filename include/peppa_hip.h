@@ -184,9 +184,11 @@ int pp_wgrad_xbn_supported(const pp_wgrad_desc* d);
  * transpose_io=1 builds the dgrad operand [Ci][taps(flipped)][cog]. */
 int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, void* out, int rows_out, int cg,
                         int transpose_io, int flip, float scale, pp_stream_t s);
-/* pp_prep_conv_weight for a DEVICE table of n weights in one launch (a tower's convolutions, both layouts).  Item = 80 bytes:
- * 9 x int64 {w (const float*), out, Co, Ci, taps, rows_out, cg, transpose_io, flip}, float scale, 4 bytes of padding */
-int pp_prep_conv_weight_multi(const void* items, int n, int blocks_per_item, pp_stream_t s);
+/* pp_prep_conv_weight for a DEVICE table of n weights in one launch (a tower's convolutions, both layouts).  Item = 88 bytes:
+ * 10 x int64 {w (const float*), out, Co, Ci, taps, rows_out, cg, transpose_io, flip, blk0}, float scale, 4 bytes of padding.
+ * One block converts 2048 consecutive elements of one `out`: item i owns blocks [blk0_i, blk0_(i+1)), blk0 ascending from 0,
+ * total_blocks = their sum */
+int pp_prep_conv_weight_multi(const void* items, int n, long long total_blocks, pp_stream_t s);
 /* out[r][i][cg] = w[r][sel[i]][cg] (bf16): tap subset of a conv operand, nsel <= 32 (sel is a HOST array) */
 int pp_select_taps(const void* w, int rows, int taps, int cg, const int* sel, int nsel, void* out, pp_stream_t s);
 /* g [Co][taps][cg] fp32 (pp_wgrad layout) -> dw [Co][Ci][taps] fp32, dw = g (beta=0) or += */

@@ -143,14 +143,23 @@ __global__ void prep_conv_kernel(const float* __restrict__ w, int Co, int Ci, in
     out[i] = f2h(v);
   }
 }
-// the same for a device table of weights in one launch (blockIdx.y = weight): a tower's ~40 convolutions x 2 layouts are
-// 4-8 us launches each on its critical stream
-struct PrepItem { const float* w; h16raw* out; long long Co, Ci, taps, rows_out, cg, transpose_io, flip; float scale; int pad; };
-__global__ __launch_bounds__(256) void prep_conv_multi_kernel(const PrepItem* __restrict__ items) {
-  const PrepItem it = items[blockIdx.y];
+// the same for a device table of weights in one launch: a tower's ~40 convolutions x 2 layouts are 4-8 us launches each on
+// its critical stream.  One block = 2048 consecutive output elements of one weight; item i owns blocks [blk0, next item's blk0).
+struct PrepItem { const float* w; h16raw* out; long long Co, Ci, taps, rows_out, cg, transpose_io, flip, blk0; float scale; int pad; };
+__global__ __launch_bounds__(256) void prep_conv_multi_kernel(const PrepItem* __restrict__ items, const int n) {
+  int lo = 0, hi = n - 1;                       // last item whose first block is <= blockIdx.x (uniform: scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].blk0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PrepItem it = items[lo];
   const int Co = (int)it.Co, Ci = (int)it.Ci, taps = (int)it.taps, cg = (int)it.cg;
-  const long long n = it.rows_out * it.taps * it.cg;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  const long long total = it.rows_out * it.taps * it.cg;
+  const long long base = ((long long)blockIdx.x - it.blk0) * 2048;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long long i = base + u * 256 + threadIdx.x;
+    if (i >= total) break;
     const int c = (int)(i % cg);
     const long long t2 = i / cg;
     int tap = (int)(t2 % taps);
@@ -344,10 +353,10 @@ extern "C" int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, voi
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
-extern "C" int pp_prep_conv_weight_multi(const void* items, int n, int blocks_per_item, pp_stream_t s) {
-  PP_CHECK_ARG(items && n > 0 && n <= 65535 && blocks_per_item > 0, "pp_prep_conv_weight_multi: bad arguments");
-  static_assert(sizeof(PrepItem) == 80, "pp_prep_item layout (9 x 8 bytes, float scale, 4 bytes of padding)");
-  hipLaunchKernelGGL(prep_conv_multi_kernel, dim3(blocks_per_item, n), dim3(256), 0, S_, (const PrepItem*)items);
+extern "C" int pp_prep_conv_weight_multi(const void* items, int n, long long total_blocks, pp_stream_t s) {
+  PP_CHECK_ARG(items && n > 0 && total_blocks > 0 && total_blocks < 0x7fffffffLL, "pp_prep_conv_weight_multi: bad arguments");
+  static_assert(sizeof(PrepItem) == 88, "pp_prep_item layout (10 x 8 bytes, float scale, 4 bytes of padding)");
+  hipLaunchKernelGGL(prep_conv_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, S_, (const PrepItem*)items, n);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -303,16 +303,16 @@ def prep_conv_weight_multi(jobs, device):
     Returns the device table and its pinned source (the caller keeps them until the launch has run)."""
     import struct
     one = struct.unpack("<q", struct.pack("<fi", 1.0, 0))[0]       # {float scale = 1, int pad} as the table's int64 word
-    rows = []
+    rows, blk0 = [], 0
     for (w, out, Co, Ci, taps, rows_out, cg, tr) in jobs:
         assert w.dtype == f32 and w.is_contiguous() and out.dtype == act16() and cg % 8 == 0
         assert (rows_out >= Ci and cg >= Co) if tr else (rows_out >= Co and cg >= Ci), "pad too small"
         assert out.numel() == rows_out * taps * cg
-        rows.append([w.data_ptr(), out.data_ptr(), Co, Ci, taps, rows_out, cg, int(tr), 0, one])
+        rows.append([w.data_ptr(), out.data_ptr(), Co, Ci, taps, rows_out, cg, int(tr), 0, blk0, one])
+        blk0 += (rows_out * taps * cg + 2047) // 2048
     host = torch.tensor(rows, dtype=torch.int64).pin_memory()
     tab = host.to(device, non_blocking=True)
-    biggest = max(j[5] * j[4] * j[6] for j in jobs)
-    call("pp_prep_conv_weight_multi", C.c_void_p(tab.data_ptr()), len(jobs), max(1, min(128, (biggest + 2047) // 2048)), _s())
+    call("pp_prep_conv_weight_multi", C.c_void_p(tab.data_ptr()), len(jobs), blk0, _s())
     return tab, host
 
 
