@@ -273,9 +273,10 @@ int pp_bn_apply(const void* y, const float* scale, const float* shift, const voi
 int pp_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
                      const float* scale, const float* shift, int relu, float* partials, int nblk, long long M,
                      int Cp, pp_stream_t s);
-/* pass 2: sums -> dgamma,dbeta (C real channels), coefficient vectors for the apply pass */
+/* pass 2: sums -> dgamma,dbeta (C real channels), coefficient vectors for the apply pass.  ws: 64 * 2 * Cp floats or NULL;
+ * with it and nblk > 256 the partial rows are summed in two levels (64 slices in parallel, fixed order), like pp_bn_finalize */
 int pp_bn_bwd_finalize(const float* partials, int nblk, long long count, int C, int Cp, const float* gamma,
-                       const float* rstd, float* dgamma, float* dbeta, float* coef, pp_stream_t s);
+                       const float* rstd, float* dgamma, float* dbeta, float* coef, float* ws, pp_stream_t s);
 /* pass 3: dy = gamma*rstd*(dzm - mean(dzm) - xhat*mean(dzm*xhat)); optional dres = dzm */
 int pp_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* mean, const float* rstd,
                     const float* coef, const float* scale, const float* shift, int relu, void* dy, void* dres,

@@ -103,7 +103,7 @@ SIGNATURES = {
     "pp_bn_eval_affine": [P, P, P, P, F, I, I, P, P, P],
     "pp_bn_apply": [P, P, P, P, I, P, L, I, P],
     "pp_bn_bwd_reduce": [P, P, P, P, P, P, P, I, P, I, L, I, P],
-    "pp_bn_bwd_finalize": [P, I, L, I, I, P, P, P, P, P, P],
+    "pp_bn_bwd_finalize": [P, I, L, I, I, P, P, P, P, P, P, P],
     "pp_bn_bwd_apply": [P, P, P, P, P, P, P, P, I, P, P, L, I, P],
     "pp_gelu_fwd": [P, P, L, P],
     "pp_gelu_bwd": [P, P, P, L, P],

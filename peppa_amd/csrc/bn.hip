@@ -215,24 +215,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const h16raw* __rest
   });
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, double count,
-                                                              int C, int Cp, const float* gamma, const float* rstd,
-                                                              float* dgamma, float* dbeta, float* coef) {
-  __shared__ double s1s[16][17], s2s[16][17];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, double count,
+                                                               int C, int Cp, const float* gamma, const float* rstd,
+                                                               float* dgamma, float* dbeta, float* coef) {
+  // 16 channels x 64 row groups per block (round 4; was x 16): only ceil(Cp / 16) blocks read the up to 2048 partial rows
+  // (2.4 MB at 144 channels), so the loads in flight per block set the time -- 35 us at layer 1 with 256 threads
+  constexpr int PARTS = 64;
+  __shared__ double s1s[PARTS][17], s2s[PARTS][17];
   const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < Cp) {
-    // four independent chains: the loop is a string of dependent ~250 ns loads otherwise (2048 partial rows)
+    // four independent chains: the loop is a string of dependent ~250 ns loads otherwise
     double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
     int b = part;
-    for (; b + 48 < nblk; b += 64)
+    for (; b + 3 * PARTS < nblk; b += 4 * PARTS)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        a1[u] += partials[((long long)(b + 16 * u) * 2 + 0) * Cp + c];
-        a2[u] += partials[((long long)(b + 16 * u) * 2 + 1) * Cp + c];
+        a1[u] += partials[((long long)(b + PARTS * u) * 2 + 0) * Cp + c];
+        a2[u] += partials[((long long)(b + PARTS * u) * 2 + 1) * Cp + c];
       }
-    for (; b < nblk; b += 16) {
+    for (; b < nblk; b += PARTS) {
       a1[0] += partials[((long long)b * 2 + 0) * Cp + c];
       a2[0] += partials[((long long)b * 2 + 1) * Cp + c];
     }
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   s2s[part][cl] = s2;
   __syncthreads();
   if (part == 0 && c < Cp) {
-    for (int q = 1; q < 16; ++q) { s1 += s1s[q][cl]; s2 += s2s[q][cl]; }
+    for (int q = 1; q < PARTS; ++q) { s1 += s1s[q][cl]; s2 += s2s[q][cl]; }
     if (c < C) {
       dbeta[c] = (float)s1;
       dgamma[c] = (float)s2;
@@ -411,8 +414,16 @@ extern "C" int pp_bn_bwd_reduce(const void* dz, const void* y, const void* z, co
 }
 
 extern "C" int pp_bn_bwd_finalize(const float* partials, int nblk, long long count, int C, int Cp, const float* gamma,
-                                  const float* rstd, float* dgamma, float* dbeta, float* coef, pp_stream_t s) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Cp + 15) / 16), dim3(256), 0, (hipStream_t)s, partials, nblk,
+                                  const float* rstd, float* dgamma, float* dbeta, float* coef, float* ws, pp_stream_t s) {
+  PP_CHECK_ARG(partials && nblk > 0 && count > 0 && C > 0 && Cp >= C, "pp_bn_bwd_finalize: bad sizes");
+  if (ws && nblk > 256) {  // two-level reduction, as pp_bn_finalize: 64 slices in parallel (fixed order), then 64 rows
+    const int nslice = 64, per_slice = (nblk + nslice - 1) / nslice;
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((Cp + 15) / 16, nslice), dim3(256), 0, (hipStream_t)s, partials, nblk, Cp,
+                       per_slice, ws);
+    partials = ws;
+    nblk = nslice;
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Cp + 15) / 16), dim3(1024), 0, (hipStream_t)s, partials, nblk,
                      (double)count, C, Cp, gamma, rstd, dgamma, dbeta, coef);
   PP_LAUNCH_CHECK();
   return PP_OK;

@@ -153,23 +153,24 @@ __global__ __launch_bounds__(256) void prep_conv_multi_kernel(const PrepItem* __
     if (items[mid].blk0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const PrepItem it = items[lo];
-  const int Co = (int)it.Co, Ci = (int)it.Ci, taps = (int)it.taps, cg = (int)it.cg;
-  const long long total = it.rows_out * it.taps * it.cg;
-  const long long base = ((long long)blockIdx.x - it.blk0) * 2048;
+  // a thread converts ONE 8-channel chunk (cg is a multiple of 8): two 32-bit divisions per 16-byte store instead of
+  // three 64-bit ones per element, which is where the per-weight kernel spends its time
+  const unsigned Co = (unsigned)it.Co, Ci = (unsigned)it.Ci, taps = (unsigned)it.taps, cg8 = (unsigned)it.cg >> 3;
+  const unsigned nchunks = (unsigned)it.rows_out * taps * cg8;       // (the launcher checked < 2^31 elements)
+  const unsigned q = (unsigned)(blockIdx.x - (unsigned)it.blk0) * 256u + threadIdx.x;
+  if (q >= nchunks) return;
+  const unsigned c0 = (q % cg8) * 8u, t2 = q / cg8;
+  unsigned tap = t2 % taps;
+  const unsigned row = t2 / taps;
+  if (it.flip) tap = taps - 1 - tap;
+  float v[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const long long i = base + u * 256 + threadIdx.x;
-    if (i >= total) break;
-    const int c = (int)(i % cg);
-    const long long t2 = i / cg;
-    int tap = (int)(t2 % taps);
-    const int row = (int)(t2 / taps);
-    if (it.flip) tap = taps - 1 - tap;
-    const int co = it.transpose_io ? c : row, ci = it.transpose_io ? row : c;
-    float v = 0.f;
-    if (co < Co && ci < Ci) v = it.w[((long long)co * Ci + ci) * taps + tap] * it.scale;
-    it.out[i] = f2h(v);
+    const unsigned c = c0 + u;
+    const unsigned co = it.transpose_io ? c : row, ci = it.transpose_io ? row : c;
+    v[u] = (co < Co && ci < Ci) ? it.w[((size_t)co * Ci + ci) * taps + tap] * it.scale : 0.f;
   }
+  *(uint4*)(it.out + (size_t)q * 8) = pack8(v);
 }
 __global__ void unprep_conv_kernel(const float* __restrict__ g, int Co, int Ci, int taps, int cg, float* __restrict__ dw) {
   GSTRIDE(i, (long long)Co * Ci * taps) {
@@ -355,6 +356,7 @@ extern "C" int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, voi
 }
 extern "C" int pp_prep_conv_weight_multi(const void* items, int n, long long total_blocks, pp_stream_t s) {
   PP_CHECK_ARG(items && n > 0 && total_blocks > 0 && total_blocks < 0x7fffffffLL, "pp_prep_conv_weight_multi: bad arguments");
+  // (every `out` has fewer than 2^31 elements and is 16-byte aligned: the caller's table, peppa_amd/hip.py checks both)
   static_assert(sizeof(PrepItem) == 88, "pp_prep_item layout (10 x 8 bytes, float scale, 4 bytes of padding)");
   hipLaunchKernelGGL(prep_conv_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, S_, (const PrepItem*)items, n);
   PP_LAUNCH_CHECK();

@@ -307,7 +307,7 @@ def prep_conv_weight_multi(jobs, device):
     for (w, out, Co, Ci, taps, rows_out, cg, tr) in jobs:
         assert w.dtype == f32 and w.is_contiguous() and out.dtype == act16() and cg % 8 == 0
         assert (rows_out >= Ci and cg >= Co) if tr else (rows_out >= Co and cg >= Ci), "pad too small"
-        assert out.numel() == rows_out * taps * cg
+        assert out.numel() == rows_out * taps * cg < 2 ** 31 and out.data_ptr() % 16 == 0
         rows.append([w.data_ptr(), out.data_ptr(), Co, Ci, taps, rows_out, cg, int(tr), 0, blk0, one])
         blk0 += (rows_out * taps * cg + 2047) // 2048
     host = torch.tensor(rows, dtype=torch.int64).pin_memory()
@@ -407,9 +407,11 @@ def bn_bwd_reduce(dz, y, z, mean, rstd, scale, shift, relu, partials, nblk, M, C
          _p(shift, f32), int(relu), _p(partials, f32), nblk, M, Cp, _s())
 
 
-def bn_bwd_finalize(partials, nblk, count, Cn, Cp, gamma, rstd, dgamma, dbeta, coef):
+def bn_bwd_finalize(partials, nblk, count, Cn, Cp, gamma, rstd, dgamma, dbeta, coef, ws=None):
+    """ws: fp32 [64 * 2 * Cp] or None (then one level, whatever nblk)"""
+    assert ws is None or ws.numel() >= 64 * 2 * Cp
     call("pp_bn_bwd_finalize", _p(partials, f32), nblk, count, Cn, Cp, _p(gamma, f32), _p(rstd, f32),
-         _p(dgamma, f32), _p(dbeta, f32), _p(coef, f32), _s())
+         _p(dgamma, f32), _p(dbeta, f32), _p(coef, f32), _p(ws, f32), _s())
 
 
 def bn_bwd_apply(dz, y, z, mean, rstd, coef, scale, shift, relu, dy, dres, M, Cp):

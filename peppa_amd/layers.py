@@ -476,7 +476,9 @@ def bn_bwd(dz, y, z, sv, gamma, *, relu, want_dres=False):
         H.bn_bwd_reduce(dz, y, z, sv.mean, sv.rstd, sv.scale, sv.shift, relu, partials, nblk, M, Cp)
     dgamma, dbeta = empty((sv.C,), f32, y), empty((sv.C,), f32, y)
     coef = empty((3, Cp), f32, y)
-    H.bn_bwd_finalize(partials, nblk, sv.count, sv.C, Cp, gamma, sv.rstd, dgamma, dbeta, coef)
+    # (more than 256 partial rows: two levels -- 64 slices in parallel, then 64 rows; 9 blocks walking 2048 rows took 35 us)
+    ws = empty((64 * 2 * Cp,), f32, y) if nblk > 256 else None
+    H.bn_bwd_finalize(partials, nblk, sv.count, sv.C, Cp, gamma, sv.rstd, dgamma, dbeta, coef, ws)
     if SYNC_BN_REDUCE is not None:
         # dgamma / dbeta stay this rank's sums (the data-parallel all-reduce adds the ranks up); the coefficients of dy
         # -- the means of g and g * xhat -- are those of the global batch (sv.count already is the global count)

@@ -87,7 +87,10 @@ def test_the_mode_changes_results_only_within_rounding(deterministic):
     H.set_deterministic(False)
     plain = _run(net, state, batch, steps=1)
     H.set_deterministic(True)
-    assert abs(det[0][0].item() - plain[0][0].item()) <= 2e-4
+    # measured spread of this difference over runs of the plain (atomic) mode: 0.6e-4 ... 2.5e-4 (tools/probe/det_vs_plain.py;
+    # bf16 activations turn a last-bit difference of an fp32 sum into 2^-9 relative steps downstream); SURVEY 8d's bf16
+    # loss tolerance against the oracle is 5e-3
+    assert abs(det[0][0].item() - plain[0][0].item()) <= 1e-3
     for n in ("audio_encoder.project.weight", "video_encoder.project.weight", "audio_encoder.audio.encoder.transformer.layers.11.feed_forward.output_dense.weight"):
         g0, g1 = det[1][n], plain[1][n]
         assert (g0 - g1).norm().item() <= 0.1 * g1.norm().item() + 1e-12, n     # (the hinge loss at random init amplifies last bits: test_model_gpu.py)
