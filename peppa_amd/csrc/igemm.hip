@@ -43,6 +43,7 @@ int pp_opt_win_partial = 1;
 int pp_opt_win_ragged = 1;
 int pp_opt_win_kpb = 2;
 int pp_opt_wgrad_group_ring = 0;
+int pp_opt_wgrad_big = 32768;        // 256 x 256 weight-gradient tiles once the reduce dimension has this many rows (0 = never)
 // BatchNorm streaming passes (tools/bench_bn.py, layer-1 shapes): non-temporal STORES + 32 k workgroups instead of plain
 // stores + 4 k: apply 417 -> 370 us, backward apply 576 -> 485 us at 144 channels (4.4 / 4.8 -> 5.0 / 5.7 TB/s); non-temporal
 // loads on top bought nothing.  bit 0: non-temporal loads, bit 1: non-temporal stores.
@@ -82,6 +83,7 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "win_ragged")) { pp_opt_win_ragged = value; return PP_OK; }
   if (!strcmp(name, "win_kpb")) { pp_opt_win_kpb = value == 2 ? 2 : 1; return PP_OK; }
   if (!strcmp(name, "wgrad_group_ring")) { pp_opt_wgrad_group_ring = value; return PP_OK; }
+  if (!strcmp(name, "wgrad_big")) { pp_opt_wgrad_big = value; return PP_OK; }
   if (!strcmp(name, "bn_nt")) { pp_opt_bn_nt = value; return PP_OK; }
   if (!strcmp(name, "win_out_nt")) { pp_opt_win_out_nt = value; return PP_OK; }
   if (!strcmp(name, "bn_grid")) { pp_opt_bn_grid = value > 0 ? value : 32768; return PP_OK; }

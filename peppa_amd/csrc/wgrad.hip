@@ -14,6 +14,7 @@ int pp_validate_gather(const pp_gather& g, int K, const char* who);
 extern int pp_opt_xcd_remap_wgrad;
 extern int pp_opt_wgrad_flat;
 extern int pp_opt_wgrad_group_ring;
+extern int pp_opt_wgrad_big;
 extern int pp_opt_ring_wgrad;
 extern int pp_opt_sw_wgrad;
 extern int pp_opt_deterministic;
@@ -341,6 +342,257 @@ __global__ __launch_bounds__(256, (WI <= 9 ? 2 : 1)) void wgrad_kernel(const pp_
           if (p.ws) p.ws[slab_w + (long long)i * p.ldw + j] = tile[row * TJ + h * 64 + lane];
           else atomicAdd(dW + (long long)i * p.ldw + j, tile[row * TJ + h * 64 + lane]);
         }
+      }
+    }
+  }
+}
+
+// ---- 256 x 256 tiles (round 4) -------------------------------------------------------------------------------------------
+// Every GEMM-shaped kernel of this library delivers 8-10 TB/s from the L2 to its CUs, whatever it does with the bytes
+// (DESIGN.md section 5): the 128 x 128 tile above asks for M * (Ni * Kj / 128 + Kj * Ni / 128) * 2 bytes, a 256 x 256 tile for
+// half of that.  Eight waves as a 2 x 4 grid of 128 x 64 wave tiles (32 MFMAs per 12 fragment reads), one workgroup per CU,
+// the same register-staged pipeline (two register sets in flight, two LDS buffers, one barrier per 64-row step).  No fused
+// bias gradient (the caller's launcher keeps the 128 x 128 kernel for that), no M split slabs (deterministic mode likewise).
+constexpr int BTI = 256, BTJ = 256;
+constexpr int BPS = BTI * 2 + 32, BQS = BTJ * 2 + 32;     // row strides in bytes: 32 x odd (conflict-free transposing reads)
+
+template <int MODE, bool BIAS>
+__global__ __launch_bounds__(512, 1) void wgrad_big_kernel(const pp_wgrad_desc p, const WGeom wg, const int nblk_i, const int nblk_j,
+                                                           const int rows_per_split, const int xcd_remap, const int flat) {
+  constexpr int P_BYTES = MS * BPS, Q_BYTES = MS * BQS, BUF = P_BYTES + Q_BYTES;
+  constexpr int NCH = 4;                                  // 16-byte chunks per thread, operand and step (64 rows x 32 chunks / 512)
+  constexpr int BIAS_BYTES = BIAS ? 512 * 8 * 4 : 0;      // the bias gradient's running sums: eight floats per thread (below)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + 1024 + 4 * MS * 8 + BIAS_BYTES];
+  static_assert(2 * BUF + 1024 + 4 * MS * 8 + BIAS_BYTES <= 160 * 1024, "LDS budget");
+  int* const lut = (int*)(smem + 2 * BUF);
+  int2* const rowtab = (int2*)(smem + 2 * BUF + 1024);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid;
+  {
+    const int nwg = gridDim.x, b0 = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = b0 & 7;
+    bid = xcd_remap ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b0 >> 3) : b0;
+  }
+  int ib, jb, split, z;
+  if (flat) {          // grouped launch, no M split: (problem, tile) in slab-sharing order (see wgrad_kernel)
+    const int tiles = nblk_i * nblk_j;
+    z = bid / tiles;
+    const int r = bid - z * tiles;
+    if (nblk_j <= nblk_i) { jb = r % nblk_j; ib = r / nblk_j; } else { ib = r % nblk_i; jb = r / nblk_i; }
+    split = 0;
+  } else {
+    ib = bid % nblk_i; bid /= nblk_i;
+    jb = bid % nblk_j; bid /= nblk_j;
+    split = bid;
+    z = blockIdx.z;
+  }
+  const h16raw* X = (const h16raw*)p.X + z * p.x_s;
+  const h16raw* dY = (const h16raw*)p.dY + z * p.dy_s;
+  float* __restrict__ dW = p.dW + z * p.dw_s;
+  float* dbias_z = BIAS ? p.dbias + z * p.dbias_s : nullptr;
+  if (p.ptr_table) {
+    const unsigned long long* e = p.ptr_table + 4 * z;
+    X = (const h16raw*)e[0];
+    dY = (const h16raw*)e[1];
+    dW = (float*)e[2];
+    dbias_z = BIAS ? (float*)e[3] : nullptr;
+  }
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, (int)OOB, 0x00020000);
+  const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)dY, (short)0, (int)OOB, 0x00020000);
+  const pp_gather& g = p.g;
+  const int ntaps = g.kt * g.kh * g.kw;
+  if (MODE != PP_DENSE) {
+    for (int tp = tid; tp < 256; tp += blockDim.x) {
+      int e = 0;
+      if (tp < ntaps) {
+        const int dw = tp % g.kw;
+        const int t2 = tp / g.kw;
+        e = (t2 / g.kh) | ((t2 % g.kh) << 8) | (dw << 16);
+      }
+      lut[tp] = e;
+    }
+    __syncthreads();
+  }
+  const int i0 = ib * BTI, j0 = jb * BTJ;
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(p.M, m_begin + rows_per_split);
+
+  // chunks owned by this thread: rows (tid >> 5) + 16 i, chunk column tid & 31 -- of Q (gathered X, columns j0 + 8 ch) and of P (dY)
+  const int crow = tid >> 5, cch = tid & 31;
+  const int jq = j0 + cch * 8;
+  const bool jq_ok = jq < p.Kj;
+  const int ip = i0 + cch * 8;
+  const bool ip_ok = ip < p.ldy;
+  int qtap = 0;
+  unsigned tapoff = 0;
+  if (MODE != PP_DENSE && jq_ok) {
+    qtap = jq / g.cg;
+    const int cc = jq % g.cg;
+    const int e = lut[qtap];
+    const int dt = e & 0xff, dh = (e >> 8) & 0xff, dw = (e >> 16) & 0xff;
+    tapoff = (unsigned)((((dt * g.Gh + dh) * g.Gw + dw) * g.cstride + cc) * 2);
+  }
+  // row table (conv gathers; the launcher only sends <= 32 taps here): see wgrad_kernel
+  auto decode_rows = [&](const int mbase, const int par) __attribute__((always_inline)) {
+    const int m = mbase + lane;
+    int base = 0;
+    unsigned mask = 0;
+    if (m < m_end) {
+      const uint32_t t1 = fdiv((uint32_t)m, wg.dRw);
+      const int rw = m - (int)t1 * g.Rw;
+      const uint32_t t2 = fdiv(t1, wg.dRh);
+      const int rh = (int)t1 - (int)t2 * g.Rh;
+      const int n = (int)fdiv(t2, wg.dRt);
+      const int rt = (int)t2 - n * g.Rt;
+      const int ct = rt * g.st - g.pt, chh = rh * g.sh - g.ph, cw = rw * g.sw - g.pw;
+      base = ((((n * g.Gt + ct) * g.Gh + chh) * g.Gw + cw) * g.cstride) * 2;
+      unsigned vw = 0, mhw = 0;
+      for (int d = 0; d < g.kw; ++d) vw |= (unsigned)((unsigned)(cw + d) < (unsigned)g.Gw) << d;
+      for (int d = 0; d < g.kh; ++d) mhw |= ((unsigned)(chh + d) < (unsigned)g.Gh) ? vw << (d * g.kw) : 0u;
+      for (int d = 0; d < g.kt; ++d) mask |= ((unsigned)(ct + d) < (unsigned)g.Gt) ? mhw << (d * g.kh * g.kw) : 0u;
+    }
+    rowtab[par * MS + lane] = make_int2(base, (int)mask);
+  };
+
+  const int wi = wave >> 2, wj = wave & 3;       // 2 x 4 wave grid: rows [128 wi, +128) x columns [64 wj, +64) of the tile
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // optional bias gradient (column sums of dY) from the P chunks this thread stages anyway: its chunk column is the same on
+  // every row, so eight running sums do; the workgroups of column block 0 own it.  The sums live in the thread's OWN 32 bytes
+  // of LDS, not in registers: eight more live registers across the K loop spill (254 + 8) and cost every workgroup of the
+  // launch 20 % (profiles/r04_probe_wgrad_big.log)
+  const bool do_bias = BIAS && jb == 0;
+  float* const bmine = (float*)(smem + 2 * BUF + 1024 + 4 * MS * 8) + tid * 8;
+  if (BIAS && do_bias) {
+    *(float4*)bmine = make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(bmine + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  u32x4 rq[2][NCH], rp[2][NCH];
+  auto load_stage = [&](const int set, const int step) __attribute__((always_inline)) {
+    const int mbase = m_begin + step * MS;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int row = crow + 16 * i;
+      unsigned off;
+      if (MODE == PP_DENSE) {
+        const int m = mbase + row;
+        off = (jq_ok && m < m_end) ? (unsigned)(m * g.lda + jq) * 2u : OOB;
+      } else {
+        const int2 e = rowtab[(step & 3) * MS + row];          // (rows past m_end carry an empty mask)
+        off = (jq_ok && (((unsigned)e.y >> qtap) & 1u)) ? (unsigned)e.x + tapoff : OOB;
+      }
+      rq[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int m = mbase + crow + 16 * i;
+      rp[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (ip_ok && m < m_end) ? (unsigned)(m * p.ldy + ip) * 2u : OOB, 0, 0);
+    }
+  };
+  auto store_stage = [&](const int set, unsigned char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *(u32x4*)(buf + (crow + 16 * i) * BPS + cch * 16) = rp[set][i];
+    if (BIAS && do_bias) {
+      float t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {          // (rows in ascending order: a fixed summation order)
+        float f[8];
+        unpack8(make_uint4(rp[set][i][0], rp[set][i][1], rp[set][i][2], rp[set][i][3]), f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] += f[q];
+      }
+      float4 lo = *(float4*)bmine, hi = *(float4*)(bmine + 4);
+      lo.x += t[0]; lo.y += t[1]; lo.z += t[2]; lo.w += t[3];
+      hi.x += t[4]; hi.y += t[5]; hi.z += t[6]; hi.w += t[7];
+      *(float4*)bmine = lo;
+      *(float4*)(bmine + 4) = hi;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *(u32x4*)(buf + P_BYTES + (crow + 16 * i) * BQS + cch * 16) = rq[set][i];
+  };
+  auto compute = [&](const unsigned char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const unsigned char* Pt = buf + sub * 32 * BPS;
+      const unsigned char* Qt = buf + P_BYTES + sub * 32 * BQS;
+      h16x8 bf[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = tr_frag(Qt, BQS, (wj * 4 + b) * 16, lane);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const h16x8 af = tr_frag(Pt, BPS, (wi * 8 + a) * 16, lane);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = PP_MFMA16(af, bf[b], acc[a][b], 0, 0, 0);
+        if ((a & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // (keep the fragment reads from piling up at the top)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int nsteps = (m_end - m_begin + MS - 1) / MS;
+  const bool use_tab = MODE != PP_DENSE;
+  if (use_tab) {
+    if (wave < 4) decode_rows(m_begin + wave * MS, wave);
+    __syncthreads();
+  }
+  load_stage(0, 0);
+  store_stage(0, smem);
+  load_stage(1, 1);
+  load_stage(0, 2);
+  __syncthreads();
+  auto iteration = [&](const int st, const int set, unsigned char* cur, unsigned char* nxt) __attribute__((always_inline)) {
+    if (use_tab && wave == (st & 3)) decode_rows(m_begin + (st + 4) * MS, st & 3);
+    compute(cur);
+    store_stage(set, nxt);
+    load_stage(set, st + 3);
+    __syncthreads();
+  };
+  for (int st = 0; st < nsteps; st += 2) {
+    iteration(st, 1, smem, smem + BUF);
+    if (st + 1 < nsteps) iteration(st + 1, 0, smem + BUF, smem);
+  }
+  if (BIAS) {
+    // the sixteen row-threads of a chunk column meet in LDS and are summed IN ROW ORDER, then one add per column
+    const float* part = (const float*)(smem + 2 * BUF + 1024 + 4 * MS * 8);      // [crow][chunk column][8] = [tid][8]
+    if (do_bias && tid < BTI) {       // (the loop's last barrier made every thread's sums visible)
+      float v = 0.f;
+      for (int r = 0; r < 16; ++r) v += part[(r * 32 + (tid >> 3)) * 8 + (tid & 7)];
+      if (i0 + tid < p.Ni) atomicAdd(dbias_z + i0 + tid, v);
+    }
+    __syncthreads();
+  }
+  // the fp32 tile through LDS, 128 rows (one wave row) per pass, so that every atomic wave-instruction adds 256 contiguous bytes
+  const int fr = lane & 15, fq = lane >> 4;
+  float* tile = (float*)smem;
+  static_assert(128 * BTJ * 4 <= 2 * BUF, "half a tile fits the loop buffers");
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass > 0) __syncthreads();
+    if (wi == pass) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tile[(a * 16 + fq * 4 + r) * BTJ + (wj * 4 + b) * 16 + fr] = acc[a][b][r];
+    }
+    __syncthreads();
+    for (int k = 0; k < 16; ++k) {
+      const int row = ((k + split * 7) & 15) * 8 + wave;       // splits start at different rows (see wgrad_kernel)
+      const int i = i0 + pass * 128 + row;
+      if (i >= p.Ni) continue;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int j = j0 + h * 64 + lane;
+        if (j < p.Kj) atomicAdd(dW + (long long)i * p.ldw + j, tile[row * BTJ + h * 64 + lane]);
       }
     }
   }
@@ -759,6 +1011,42 @@ int launch_wi(const pp_wgrad_desc& d, hipStream_t s, long long* ws_query = nullp
   return PP_OK;
 }
 
+int launch_big(const pp_wgrad_desc& d, hipStream_t s) {
+  const int nblk_i = (d.Ni + BTI - 1) / BTI;
+  const int nblk_j = (d.Kj + BTJ - 1) / BTJ;
+  const long long steps = ((long long)d.M + MS - 1) / MS;
+  const long long tiles = (long long)nblk_i * nblk_j * d.nbatch;
+  // one workgroup per CU: the M split that fills whole rounds of 256 workgroups best, >= 16 steps per split
+  long long best = 1;
+  double best_eff = 0.0;
+  const long long maxs = steps / 16 > 0 ? steps / 16 : 1;
+  for (long long ms = 1; ms <= maxs && ms * tiles <= 4096; ++ms) {
+    const long long gx = ms * tiles;
+    const double eff = (double)gx / (double)(((gx + 255) / 256) * 256) - 0.002 * (double)ms;
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = ms; }
+  }
+  int msplit = d.msplit > 0 ? d.msplit : (int)best;
+  const int flat = d.ptr_table ? 1 : 0;          // grouped: every tile reduces its whole M
+  if (flat) msplit = 1;
+  const long long sps = (steps + msplit - 1) / msplit;
+  msplit = (int)((steps + sps - 1) / sps);
+  const int rows_per_split = (int)(sps * MS);
+  WGeom wg;
+  wg.dRw = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rw));
+  wg.dRh = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rh));
+  wg.dRt = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.Rt));
+  const long long gx = (long long)nblk_i * nblk_j * msplit;
+  dim3 grid((unsigned)(flat ? gx * d.nbatch : gx), 1, (unsigned)(flat ? 1 : d.nbatch)), block(512);
+  if (d.g.mode == PP_DENSE) {
+    if (d.dbias) hipLaunchKernelGGL((wgrad_big_kernel<PP_DENSE, true>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad, flat);
+    else hipLaunchKernelGGL((wgrad_big_kernel<PP_DENSE, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad, flat);
+  } else {
+    hipLaunchKernelGGL((wgrad_big_kernel<PP_CONV_FWD, false>), grid, block, 0, s, d, wg, nblk_i, nblk_j, rows_per_split, pp_opt_xcd_remap_wgrad, flat);
+  }
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
 template <int WI, int NWV>
 int launch_ring(const pp_wgrad_desc& d, hipStream_t s) {
   constexpr int TJR = 32 * NWV;
@@ -849,6 +1137,24 @@ static int wgrad_dispatch(const pp_wgrad_desc* dp, pp_stream_t stream, long long
     if (rc_tw != 1) return rc_tw;
   }
   const int n16 = (d.Ni + 15) / 16;
+  // 256 x 256 tiles (round 4; pp_opt_wgrad_big = the M from which every eligible problem takes them, 0 = never): half the L2
+  // traffic of the 128 x 128 tiles.  Not in deterministic mode (no slabs), <= 32 taps (row table), and only where the tiles
+  // fill the chip: a single problem splits M to do so; a grouped launch (no split) needs >= 0.6 of its last round of 256.
+  if (pp_opt_wgrad_big && !pp_opt_deterministic && d.Ni >= 192 && d.Kj >= 192 &&
+      (d.g.mode == PP_DENSE || d.g.kt * d.g.kh * d.g.kw <= 32) && (d.nbatch == 1 || d.ptr_table)) {
+    const long long tiles = (long long)((d.Ni + BTI - 1) / BTI) * ((d.Kj + BTJ - 1) / BTJ);
+    bool take;
+    if (d.ptr_table) {
+      const long long all = tiles * d.nbatch;
+      take = d.M >= 4096 && (double)all / (double)(((all + 255) / 256) * 256) >= 0.6;
+    } else {
+      take = (long long)d.M >= pp_opt_wgrad_big || (tiles >= 32 && d.M >= 4096);
+    }
+    if (take) {
+      if (ws_query) { *ws_query = 0; return PP_OK; }
+      return launch_big(d, s);
+    }
+  }
   if (d.ptr_table && pp_opt_wgrad_group_ring && d.g.mode == PP_DENSE && n16 > 4 && d.M >= 1024) {
     // grouped Linear weight gradients on the ring form: 128 / 144 x 192 / 256 tiles of dW (eight waves, one workgroup per CU)
     // halve the number of tiles that re-read a dY / X slab against the 128 x 128 tiles of the register-staged kernel; every

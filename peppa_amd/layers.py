@@ -477,7 +477,9 @@ def bn_bwd(dz, y, z, sv, gamma, *, relu, want_dres=False):
     dgamma, dbeta = empty((sv.C,), f32, y), empty((sv.C,), f32, y)
     coef = empty((3, Cp), f32, y)
     # (more than 256 partial rows: two levels -- 64 slices in parallel, then 64 rows; 9 blocks walking 2048 rows took 35 us)
-    ws = empty((64 * 2 * Cp,), f32, y) if nblk > 256 else None
+    # (not in deterministic mode: the first level sums in fp32 over slices of THIS rank's rows, and the mode promises the same
+    # bits for one process on the global batch and for any number of ranks -- there the rows are walked in one double-precision pass)
+    ws = empty((64 * 2 * Cp,), f32, y) if nblk > 256 and not H.DETERMINISTIC else None
     H.bn_bwd_finalize(partials, nblk, sv.count, sv.C, Cp, gamma, sv.rstd, dgamma, dbeta, coef, ws)
     if SYNC_BN_REDUCE is not None:
         # dgamma / dbeta stay this rank's sums (the data-parallel all-reduce adds the ranks up); the coefficients of dy

@@ -1578,3 +1578,54 @@ def test_one_launch_weight_preparation_matches_the_per_convolution_launches():
             assert torch.equal(wf, rf)
             assert (wd is None and rd is None) if not sh[6] else torch.equal(wd, rd)
     L.PrepPlan._plans.pop(("test-prep-plan",), None)
+
+
+@pytest.mark.parametrize("case", [
+    ("dense", 1000, 768, 768), ("dense", 7296, 2304, 768), ("dense", 4101, 520, 3072), ("dense", 333, 200, 264),
+    ("conv", 2, 512, 512, (3, 1, 1), (2, 1, 1), (0, 0, 0), (1001, 1, 1)),          # wav2vec2 feature extractor, k = 3 stride 2
+    ("conv", 3, 512, 512, (2, 1, 1), (2, 1, 1), (0, 0, 0), (459, 1, 1)),
+    ("conv", 2, 64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), (4, 28, 28)),             # layer 2.0 strided spatial (padding, ragged Ni)
+    ("conv", 2, 256, 921, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 14, 14)),
+    ("conv", 2, 576, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 7, 9)),
+])
+def test_wide_tile_weight_gradient_matches_the_128_tile_kernel_and_torch(case):
+    """pp_wgrad's 256 x 256 tiles (wgrad_big_kernel, round 4: half the L2 traffic of the 128 x 128 tiles) against the
+    128 x 128 kernel on the same operands (fp32 summation order only: the M splits differ) and, for the dense cases, against
+    torch in fp32; the grouped launch with the fused bias gradient is bitwise the 128-tile one (no M split in either)."""
+    torch.manual_seed(5)
+    H.set_option("sw_wgrad", 0)            # (the sliding-window kernels would take the stride-1 convolutions)
+    try:
+        if case[0] == "dense":
+            _, M, N, K = case
+            x = torch.randn(M, K, device="cuda").bfloat16()
+            dy = torch.randn(M, N, device="cuda").bfloat16()
+            H.set_option("wgrad_big", 0)
+            ref, rb = [t.clone() for t in L.linear_wgrad(x, dy, M, N, K)]
+            H.set_option("wgrad_big", 1)
+            got, gb = [t.clone() for t in L.linear_wgrad(x, dy, M, N, K)]
+            want = dy.float().t() @ x.float()
+            scale = want.abs().max().item()
+            assert (got - ref).abs().max().item() <= 2e-5 * scale
+            assert (got - want).abs().max().item() <= 2e-5 * scale
+            assert (gb - rb).abs().max().item() <= 2e-5 * rb.abs().max().item()
+            assert (gb - dy.float().sum(0)).abs().max().item() <= 2e-5 * rb.abs().max().item() + 1e-3
+            if M >= 4096:           # grouped launches: no M split, bitwise equal including the bias gradient
+                items = [(torch.randn(M, K, device="cuda").bfloat16(), torch.randn(M, N, device="cuda").bfloat16()) for _ in range(3)]
+                big = [(a.clone(), b.clone()) for a, b in L.linear_wgrad_group(items, M, N, K)]
+                H.set_option("wgrad_big", 0)
+                small = [(a.clone(), b.clone()) for a, b in L.linear_wgrad_group(items, M, N, K)]
+                for (a, b), (c, d) in zip(big, small):
+                    assert torch.equal(a, c) and torch.equal(b, d)
+        else:
+            _, B, Ci, Co, k, st, pd, thw = case
+            geom = L.ConvGeom(B, thw, Ci, Co, k, st, pd)
+            x = torch.randn(geom.Min, geom.in_cstride, device="cuda").bfloat16()
+            dy = torch.randn(geom.M, geom.out_cstride, device="cuda").bfloat16()
+            H.set_option("wgrad_big", 0)
+            ref = L.conv_wgrad_raw(x, dy, geom).clone()
+            H.set_option("wgrad_big", 1)
+            got = L.conv_wgrad_raw(x, dy, geom).clone()
+            assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    finally:
+        H.set_option("wgrad_big", 32768)
+        H.set_option("sw_wgrad", 4096)

@@ -11,7 +11,7 @@ if os.environ.get("MASKED_STRIDED_DGRAD"):
 B = int(os.environ.get("B", "64"))
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 case_filter = os.environ.get("CASE", "")
-for opt in ("xcd_remap_igemm", "xcd_remap_wgrad", "persistent_igemm", "ring_igemm", "ring_wgrad", "sw_wgrad", "win_igemm", "win_tall", "win_temporal", "win_out_nt", "ring_wn", "win_producers", "tw_producers", "tw_narrow", "ring_producers", "win_kpb", "win_s2d", "wgrad_flat"):
+for opt in ("xcd_remap_igemm", "xcd_remap_wgrad", "persistent_igemm", "ring_igemm", "ring_wgrad", "sw_wgrad", "win_igemm", "win_tall", "win_temporal", "win_out_nt", "ring_wn", "win_producers", "tw_producers", "tw_narrow", "ring_producers", "win_kpb", "win_s2d", "wgrad_flat", "wgrad_big"):
     if opt.upper() in os.environ:
         H.set_option(opt, int(os.environ[opt.upper()]))
 
