@@ -12,7 +12,7 @@ FAMILIES = [
     ("generic / ring implicit GEMM (igemm)", r"igemm_kernel"),
     ("sliding-window wgrad (wgrad_sw)", r"wgrad_sw_kernel"),
     ("temporal-window wgrad (wgrad_tw)", r"wgrad_tw_kernel"),
-    ("generic wgrad (incl. grouped)", r"wgrad_kernel|wgrad_slab"),
+    ("generic wgrad (incl. grouped, 256 x 256 tiles)", r"wgrad_kernel|wgrad_big_kernel|wgrad_slab"),
     ("BatchNorm apply", r"bn_apply_kernel"),
     ("BatchNorm backward reduce", r"bn_bwd_reduce_kernel"),
     ("BatchNorm backward apply", r"bn_bwd_apply_kernel"),

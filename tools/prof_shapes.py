@@ -21,7 +21,7 @@ import re
 import sys
 
 PEAK = 2.5e15
-GEMM_RE = re.compile(r"\b(igemm_win_kernel|igemm_kernel|wgrad_kernel|wgrad_sw_kernel|wgrad_tw_kernel|wgrad_ring_kernel|wgrad_group_kernel)<")
+GEMM_RE = re.compile(r"\b(igemm_win_kernel|igemm_kernel|wgrad_kernel|wgrad_big_kernel|wgrad_sw_kernel|wgrad_tw_kernel|wgrad_ring_kernel|wgrad_group_kernel)<")
 
 
 def short(name):
