@@ -72,7 +72,12 @@ int pp_experimental_build(void);
  *   "bn_nt" b, "bn_grid" n   BatchNorm streaming passes: non-temporal loads (bit 0) / stores (bit 1), workgroups per launch
  *   "persist_cus"  n   workgroups of the persistent ring / window kernels (8..256, default 256 = one per CU)
  *   "wgrad_flat"   0/1 grouped weight gradients (pp_wgrad_desc.ptr_table) walk (problem, tile) as one flat grid in
- *                      slab-sharing order (default 1; 0 = one problem per grid.z slice, round 3's order) */
+ *                      slab-sharing order (default 1; 0 = one problem per grid.z slice, round 3's order)
+ *   "wgrad_big"    m   pp_wgrad on 256 x 256 tiles for problems that fill the chip with them and whose reduce dimension has
+ *                      at least m rows (default 32768; grouped launches and problems of >= 32 tiles from 4096; 0 = never);
+ *                      never in deterministic mode
+ *   "igemm_big"    m   pp_igemm on 256 x 256 tiles from M = |m| for problems of >= 192 tiles: m > 0 plain epilogues only,
+ *                      m < 0 fused ones too; bit-identical to the default kernels (default 0 = never: DESIGN.md section 8) */
 int pp_set_option(const char* name, int value);
 const char* pp_last_error(void);
 

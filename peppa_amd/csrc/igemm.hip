@@ -43,6 +43,8 @@ int pp_opt_win_partial = 1;
 int pp_opt_win_ragged = 1;
 int pp_opt_win_kpb = 2;
 int pp_opt_wgrad_group_ring = 0;
+int pp_opt_igemm_big = 0;         // 256 x 256 forward / data-gradient tiles from this M; > 0: plain epilogues only, < 0: fused ones too.  OFF: bit-identical
+                                  // and 15 % faster alone on the audio convolutions' data gradients, no change of the step (they have slack)
 int pp_opt_wgrad_big = 32768;        // 256 x 256 weight-gradient tiles once the reduce dimension has this many rows (0 = never)
 // BatchNorm streaming passes (tools/bench_bn.py, layer-1 shapes): non-temporal STORES + 32 k workgroups instead of plain
 // stores + 4 k: apply 417 -> 370 us, backward apply 576 -> 485 us at 144 channels (4.4 / 4.8 -> 5.0 / 5.7 TB/s); non-temporal
@@ -84,6 +86,7 @@ extern "C" int pp_set_option(const char* name, int value) {
   if (!strcmp(name, "win_kpb")) { pp_opt_win_kpb = value == 2 ? 2 : 1; return PP_OK; }
   if (!strcmp(name, "wgrad_group_ring")) { pp_opt_wgrad_group_ring = value; return PP_OK; }
   if (!strcmp(name, "wgrad_big")) { pp_opt_wgrad_big = value; return PP_OK; }
+  if (!strcmp(name, "igemm_big")) { pp_opt_igemm_big = value; return PP_OK; }
   if (!strcmp(name, "bn_nt")) { pp_opt_bn_nt = value; return PP_OK; }
   if (!strcmp(name, "win_out_nt")) { pp_opt_win_out_nt = value; return PP_OK; }
   if (!strcmp(name, "bn_grid")) { pp_opt_bn_grid = value > 0 ? value : 32768; return PP_OK; }
@@ -701,6 +704,276 @@ __global__ __launch_bounds__(64 * NW + (PROD ? 256 : 0), (RING ? 1 : (WN <= 9 ? 
   }
 }
 
+// ---- 256 x 256 tiles (round 4) -------------------------------------------------------------------------------------------
+// Every GEMM-shaped kernel of this library runs at 8-10 TB/s of L2 -> CU traffic, so a large-M problem
+// goes as fast as its tile makes bytes per FLOP small: the 256 x 128 ring tile reads A once per 128 columns, this one once per
+// 256.  Eight waves as a 2 x 4 grid of 128 x 64 wave tiles (32 MFMAs per 12 fragment reads), one workgroup per CU, operands
+// register-staged with two register sets in flight and two LDS buffers (the form that beat the LDS-DMA ring for the weight
+// gradient, wgrad.hip), one tile per workgroup.  Gathers: dense, conv-forward (any stride) and unit-stride conv data gradient
+// with at most 32 taps -- the row's origin and the validity of each tap sit in a per-tile LDS table, a K-step adds the tap's
+// linear offset.  Epilogue: bias / activation / pre-activation copy / dropout / residual / output row map, bf16 output.
+constexpr int GBM = 256, GBN = 256;
+
+struct BigArgs {
+  FastDiv dcg;          // k -> (tap, channel): tap = k / cg
+};
+
+template <int MODE, bool FULL>
+__global__ __launch_bounds__(512, 1) void igemm_big_kernel(const pp_igemm_desc p, const RowDiv rd, const BigArgs ba, const int nblk_n,
+                                                           const int ntiles, const int xcd_remap, const int out_nt) {
+  constexpr int A_BYTES = GBM * 128, B_BYTES = GBN * 128, BUF = A_BYTES + B_BYTES;
+  constexpr int STG_STRIDE = 64 * 2 + 16;
+  constexpr int NCH = 4;        // 16-byte chunks per thread, operand and K-step (256 rows x 8 chunks / 512)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + 2048 + GBM * 8];
+  static_assert(2 * BUF + 2048 + GBM * 8 <= 160 * 1024 && 8 * 16 * STG_STRIDE <= BUF, "LDS budget");
+  int* const lut_off = (int*)(smem + 2 * BUF);                 // byte offset of each tap inside the source tensor
+  int2* const rowtab = (int2*)(smem + 2 * BUF + 2048);         // per tile row: {origin byte offset, tap validity mask}
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tile;
+  {
+    const int b0 = blockIdx.x, xq = ntiles >> 3, xr = ntiles & 7, xcd = b0 & 7;
+    tile = (xcd_remap && ntiles >= 8) ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b0 >> 3) : b0;
+  }
+  const int nb = tile % nblk_n, mb = tile / nblk_n;       // (the column tiles of a row block are neighbours on one XCD)
+  const h16raw* A = (const h16raw*)p.A;
+  const h16raw* Bt = (const h16raw*)p.Bt;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, (int)OOB, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bt, (short)0, (int)OOB, 0x00020000);
+  const pp_gather& g = p.g;
+  const int ntaps = g.kt * g.kh * g.kw;
+  if (MODE != PP_DENSE) {
+    if (tid < 32) {
+      int o = 0;
+      if (tid < ntaps) {
+        const int dw = tid % g.kw;
+        const int t2 = tid / g.kw;
+        o = (((t2 / g.kh) * g.Gh + (t2 % g.kh)) * g.Gw + dw) * g.cstride * 2;
+      }
+      lut_off[tid] = o;
+    }
+    if (tid < GBM) {       // this tile's row table
+      const int m = mb * GBM + tid;
+      int base = 0;
+      unsigned mask = 0;
+      if (m < p.M) {
+        const uint32_t t1 = fdiv((uint32_t)m, rd.dRw);
+        const int rw = m - (int)t1 * g.Rw;
+        const uint32_t t2 = fdiv(t1, rd.dRh);
+        const int rh = (int)t1 - (int)t2 * g.Rh;
+        const int n = (int)fdiv(t2, rd.dRt);
+        const int rt = (int)t2 - n * g.Rt;
+        // origin of the row's taps; forward: tap d sits at origin + d, data gradient (unit stride): at origin - d
+        const int ct = MODE == PP_CONV_FWD ? rt * g.st - g.pt : rt + g.pt;
+        const int chh = MODE == PP_CONV_FWD ? rh * g.sh - g.ph : rh + g.ph;
+        const int cw = MODE == PP_CONV_FWD ? rw * g.sw - g.pw : rw + g.pw;
+        const int sgn = MODE == PP_CONV_FWD ? 1 : -1;
+        base = ((((n * g.Gt + ct) * g.Gh + chh) * g.Gw + cw) * g.cstride) * 2;
+        unsigned vw = 0, mhw = 0;
+        for (int d = 0; d < g.kw; ++d) vw |= (unsigned)((unsigned)(cw + sgn * d) < (unsigned)g.Gw) << d;
+        for (int d = 0; d < g.kh; ++d) mhw |= ((unsigned)(chh + sgn * d) < (unsigned)g.Gh) ? vw << (d * g.kw) : 0u;
+        for (int d = 0; d < g.kt; ++d) mask |= ((unsigned)(ct + sgn * d) < (unsigned)g.Gt) ? mhw << (d * g.kh * g.kw) : 0u;
+      }
+      rowtab[tid] = make_int2(base, (int)mask);
+    }
+    __syncthreads();
+  }
+
+  // chunks owned by this thread: chunk column kq of rows lrow + 64 i, of A (gathered rows) and of Bt (output columns).
+  // Nothing per row is kept in registers across the K loop (128 accumulators + two register sets of 8 chunks leave no room):
+  // a K-step re-reads the rows' table entries from LDS and rebuilds the Bt offsets from two scalars.
+  const int kq = tid & 7, lrow = tid >> 3;
+  if (MODE == PP_DENSE) {       // the row table of a dense operand: {byte offset of the row or OOB, -}
+    if (tid < GBM) {
+      const int m = mb * GBM + tid;
+      rowtab[tid] = make_int2(m < p.M ? (int)((unsigned)(m * g.lda) * 2u) : (int)OOB, 0);
+    }
+    __syncthreads();
+  }
+  const int nb0 = nb * GBN + lrow;
+  const int wi = wave >> 2, wj = wave & 3;       // 2 x 4 wave grid: rows [128 wi, +128) x columns [64 wj, +64) of the tile
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[2][NCH], rb[2][NCH];
+  auto load_stage = [&](const int set, const int step) __attribute__((always_inline)) {
+    const int k = step * BK + kq * 8;
+    const bool k_ok = k < p.K;
+    unsigned koff = (unsigned)k * 2u;
+    unsigned tapbit = 0;
+    if (MODE != PP_DENSE) {
+      const int tap = (int)fdiv((uint32_t)k, ba.dcg);
+      const int cch = k - tap * g.cg;
+      const unsigned lo = (unsigned)lut_off[tap & 31];
+      koff = MODE == PP_CONV_FWD ? lo + (unsigned)cch * 2u : (unsigned)cch * 2u - lo;
+      tapbit = k_ok ? 1u << (tap & 31) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int2 e = rowtab[lrow + 64 * i];
+      unsigned off;
+      if (MODE == PP_DENSE) off = (k_ok && (unsigned)e.x != OOB) ? (unsigned)e.x + koff : OOB;
+      else off = ((unsigned)e.y & tapbit) ? (unsigned)e.x + koff : OOB;
+      ra[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int n = nb0 + 64 * i;
+      rb[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (k_ok && n < p.b_rows) ? (unsigned)(n * p.ldb + k) * 2u : OOB, 0, 0);
+    }
+  };
+  auto store_stage = [&](const int set, unsigned char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int r = lrow + 64 * i;
+      *(u32x4*)(buf + r * 128 + ((kq ^ swz(r)) << 4)) = ra[set][i];
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int r = lrow + 64 * i;
+      *(u32x4*)(buf + A_BYTES + r * 128 + ((kq ^ swz(r)) << 4)) = rb[set][i];
+    }
+  };
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](const unsigned char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fsw = ((ks * 4 + fq) ^ swz(fr)) << 4;      // (swz(row) only sees the row's low four bits)
+      h16x8 bf[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = *(const h16x8*)(buf + A_BYTES + (wj * 64 + b * 16 + fr) * 128 + fsw);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const h16x8 af = *(const h16x8*)(buf + (wi * 128 + a * 16 + fr) * 128 + fsw);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = PP_MFMA16(af, bf[b], acc[a][b], 0, 0, 0);
+        if ((a & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // (keep the fragment reads from piling up at the top)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // pipeline: K-step s is loaded into register set s & 1 three iterations ahead, written to LDS buffer s & 1 after step s - 1
+  // has been multiplied, multiplied one iteration later (loads past the last step fetch nothing)
+  const int nk = (p.K + BK - 1) / BK;
+  load_stage(0, 0);
+  store_stage(0, smem);
+  load_stage(1, 1);
+  load_stage(0, 2);
+  __syncthreads();
+  auto iteration = [&](const int st, const int set, unsigned char* cur, unsigned char* nxt) __attribute__((always_inline)) {
+    compute(cur);
+    store_stage(set, nxt);
+    load_stage(set, st + 3);
+    __syncthreads();
+  };
+  for (int st = 0; st < nk; st += 2) {
+    iteration(st, 1, smem, smem + BUF);
+    if (st + 1 < nk) iteration(st + 1, 0, smem + BUF, smem);
+  }
+
+  // ---- epilogue: same order of operations and roundings as igemm_kernel's (bias, [pre-activation copy], activation, bf16,
+  // dropout, residual); each wave stages 16 x 64 of its tile at a time and writes whole 16-byte row segments
+  const int ncols_store = (p.N + 7) & ~7;
+  const uint32_t drop_thr = FULL ? (uint32_t)(p.drop_p * 65536.f + 0.5f) : 0u;
+  const float drop_scale = 1.f / (1.f - p.drop_p);
+  const int m_wave = mb * GBM + wi * 128, n_wave = nb * GBN + wj * 64;
+  if (FULL && p.bias) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int n = n_wave + b * 16 + fr;
+      const float bv = n < p.N ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] += bv;
+    }
+  }
+  unsigned char* stg = smem + wave * 16 * STG_STRIDE;       // (wave-private; the loop's last barrier freed the buffers)
+  unsigned char* stg_w = stg + (fq * 4) * STG_STRIDE + fr * 2;
+  auto write_out = [&](h16raw* Cout, const h16raw* residual) __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {      // (unrolled: a rolled loop indexes the accumulators dynamically, i.e. through scratch)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *(h16raw*)(stg_w + r * STG_STRIDE + b * 32) = f2h(acc[a][b][r]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int cid = lane + 64 * it;
+        const int row = cid >> 3, ch = cid & 7;
+        const int m = m_wave + a * 16 + row;
+        const int col = n_wave + ch * 8;
+        if (m < p.M && col < ncols_store) {
+          uint4 v = *(const uint4*)(stg + row * STG_STRIDE + ch * 16);
+          long long orow = m;
+          if (MODE != PP_DENSE && p.omap) {   // scatter compact rows of a parity class into the full tensor
+            const uint32_t t1 = fdiv((uint32_t)m, rd.dRw);
+            const int rw = m - (int)t1 * g.Rw;
+            const uint32_t t2 = fdiv(t1, rd.dRh);
+            const int rh = (int)t1 - (int)t2 * g.Rh;
+            const int n = (int)fdiv(t2, rd.dRt);
+            const int rt = (int)t2 - n * g.Rt;
+            orow = (((long long)n * p.Ot + rt * p.os_t + p.oo_t) * p.Oh + rh * p.os_h + p.oo_h) * p.Ow + rw * p.os_w + p.oo_w;
+          }
+          if (FULL && drop_thr && Cout == (h16raw*)p.C) {   // (not the pre-activation copy)
+            float x[8];
+            bool keep[8];
+            unpack8(v, x);
+            keep8(p.drop_seed, (orow * p.ldc + col) >> 3, drop_thr, keep);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = keep[q] ? x[q] * drop_scale : 0.f;
+            v = pack8(x);
+          }
+          if (FULL && residual) {
+            const uint4 rv = *(const uint4*)(residual + orow * p.ldr + col);
+            float x[8], y[8];
+            unpack8(v, x);
+            unpack8(rv, y);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] += y[q];
+            v = pack8(x);
+          }
+          if (out_nt) {
+            u32x4 w = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w, (u32x4*)(Cout + orow * p.ldc + col));
+          } else {
+            *(uint4*)(Cout + orow * p.ldc + col) = v;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  if (FULL) {
+    if (p.Cpre) write_out((h16raw*)p.Cpre, nullptr);
+    if (p.act == PP_ACT_GELU) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[a][b][r] = gelu_f(acc[a][b][r]);
+    } else if (p.act == PP_ACT_RELU) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaxf(acc[a][b][r], 0.f);
+    }
+    write_out((h16raw*)p.C, (const h16raw*)p.residual);
+  } else {
+    write_out((h16raw*)p.C, nullptr);
+  }
+}
+
 int pick_wn(int n16) {
   // padded tile count weighted by a per-shape efficiency guess (narrow tiles re-read A more often)
   static const int cand[] = {15, 9, 8, 4, 3, 2};
@@ -806,6 +1079,50 @@ int launch_ring(const pp_igemm_desc& d, hipStream_t s) {
   return PP_OK;
 }
 
+// does the 256 x 256 tile take this problem?  (pp_opt_igemm_big = the M from which it does, 0 = never)
+bool igemm_big_ok(const pp_igemm_desc& d) {
+  const pp_gather& g = d.g;
+  if (!pp_opt_igemm_big || (long long)d.M < (pp_opt_igemm_big < 0 ? -pp_opt_igemm_big : pp_opt_igemm_big)) return false;
+  if (d.c_fp32 || d.nbatch != 1 || d.inner != 1 || d.colstats || d.a_bn_scale || d.a_bn_shift) return false;
+  // fused epilogues (bias / activation / pre-activation copy / dropout / residual) are built and bit-identical, but one tile
+  // per workgroup leaves their two staged outputs uncovered: the audio convolutions' forward (GELU + the saved
+  // pre-activation) measured 627 -> 618 / 254 -> 289 us, so only plain epilogues are sent here (a NEGATIVE option value
+  // sends the fused ones too: tools/probe/igemm_big.py)
+  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;
+  if (full && pp_opt_igemm_big > 0) return false;
+  if (d.K < 2 * BK || d.N < 192) return false;
+  if (g.mode != PP_DENSE) {
+    if (g.kt * g.kh * g.kw > 32) return false;
+    if (g.mode == PP_CONV_DGRAD && !(g.st == 1 && g.sh == 1 && g.sw == 1)) return false;
+  }
+  const long long tiles = (((long long)d.M + GBM - 1) / GBM) * ((d.N + GBN - 1) / GBN);
+  return tiles >= 192;       // (at least three quarters of the CUs busy; M >= 32 768 makes that >= 128 row blocks anyway)
+}
+
+int launch_igemm_big(const pp_igemm_desc& d, hipStream_t s) {
+  const int nblk_n = (d.N + GBN - 1) / GBN;
+  const long long ntiles = (((long long)d.M + GBM - 1) / GBM) * nblk_n;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) { pp_set_error("pp_igemm: grid too large"); return PP_ERR_INVALID; }
+  const RowDiv rd = make_rowdiv(d);
+  BigArgs ba;
+  ba.dcg = make_fastdiv((uint32_t)(d.g.mode == PP_DENSE ? 1 : d.g.cg));
+  const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;
+  dim3 grid((unsigned)ntiles), block(512);
+#define PP_LAUNCH_BIG(MODE_)                                                                                                            \
+  do {                                                                                                                                  \
+    if (full) hipLaunchKernelGGL((igemm_big_kernel<MODE_, true>), grid, block, 0, s, d, rd, ba, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, out_nt_for(d)); \
+    else hipLaunchKernelGGL((igemm_big_kernel<MODE_, false>), grid, block, 0, s, d, rd, ba, nblk_n, (int)ntiles, pp_opt_xcd_remap_igemm, out_nt_for(d));     \
+  } while (0)
+  switch (d.g.mode) {
+    case PP_DENSE: PP_LAUNCH_BIG(PP_DENSE); break;
+    case PP_CONV_FWD: PP_LAUNCH_BIG(PP_CONV_FWD); break;
+    default: PP_LAUNCH_BIG(PP_CONV_DGRAD); break;
+  }
+#undef PP_LAUNCH_BIG
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
 }  // namespace
 
 int pp_validate_gather(const pp_gather& g, int K, const char* who) {
@@ -897,6 +1214,10 @@ extern "C" int pp_igemm(const pp_igemm_desc* dp, pp_stream_t stream) {
   if (pp_opt_win_igemm && (long long)d.M >= pp_opt_win_igemm) {   // (1,3,3) stride-1 convs: A window in LDS
     const int rc_win = pp_igemm_win_try(d, s);
     if (rc_win != 1) return rc_win;
+  }
+  if (igemm_big_ok(d)) {      // large-M problems: 256 x 256 tiles (half the L2 traffic of the ring tile per FLOP)
+    const int r = launch_igemm_big(d, s);
+    return (r == PP_OK && d.bnr_partials) ? PP_BNR_SKIPPED : r;
   }
   const int n16 = (d.N + 15) / 16;
   const bool full = d.bias || d.act != PP_ACT_NONE || d.residual || d.Cpre || d.drop_p > 0.f;

@@ -1629,3 +1629,59 @@ def test_wide_tile_weight_gradient_matches_the_128_tile_kernel_and_torch(case):
     finally:
         H.set_option("wgrad_big", 32768)
         H.set_option("sw_wgrad", 4096)
+
+
+def test_wide_tile_forward_and_data_gradient_are_bit_identical_to_the_default_kernels():
+    """pp_igemm's 256 x 256 tiles (igemm_big_kernel, pp_set_option igemm_big; off by default -- DESIGN.md section 8): the same
+    K order and the same epilogue roundings as the ring / gather kernels, so the results are the same bits: strided
+    convolution forward with GELU + the saved pre-activation, the parity classes of a strided data gradient (output row map),
+    a padded 3-D strided convolution, and a dense GEMM with bias / GELU / dropout / residual, ragged M, N and K."""
+    torch.manual_seed(11)
+
+    def both(fn):
+        H.set_option("igemm_big", 0)
+        ref = fn()
+        H.set_option("igemm_big", -1)          # (negative: fused epilogues too; |value| = minimum M)
+        try:
+            got = fn()
+        finally:
+            H.set_option("igemm_big", 0)
+        return ref, got
+
+    for B, k, T in ((5, 3, 9999), (7, 2, 7001)):
+        geom = L.ConvGeom(B, (T, 1, 1), 512, 512, (k, 1, 1), (2, 1, 1), (0, 0, 0))
+        x = torch.randn(geom.Min, 512, device="cuda").bfloat16()
+        dy = torch.randn(geom.M, 512, device="cuda").bfloat16()
+        w = torch.randn(512, 512, k, 1, 1, device="cuda") * 0.03
+        wf, wd = L.prep_conv_weights(w, geom)
+
+        def fwd():
+            pre = L.empty((geom.M, 512), torch.bfloat16, x)
+            y, _ = L.conv_fwd(x, geom, wf, act=H.ACT_GELU, pre=pre)
+            return y.clone(), pre.clone()
+        (y0, p0), (y1, p1) = both(fwd)
+        assert torch.equal(y0, y1) and torch.equal(p0, p1)
+        assert y0.float().abs().max().item() > 0.1
+        d0, d1 = both(lambda: L.conv_dgrad(dy, geom, wd).clone())
+        assert torch.equal(d0, d1)
+    geom = L.ConvGeom(8, (8, 56, 56), 64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    x = torch.randn(geom.Min, geom.in_cstride, device="cuda").bfloat16()
+    wf, _ = L.prep_conv_weights(torch.randn(230, 64, 1, 3, 3, device="cuda") * 0.05, geom)
+    y0, y1 = both(lambda: L.conv_fwd(x, geom, wf)[0].clone())
+    assert torch.equal(y0, y1)
+    M, N, K = 50011, 776, 520
+    wl = torch.randn(N, K, device="cuda") * 0.05
+    wfl, _ = L.prep_linear(wl)
+    xp = torch.zeros(M, wfl.shape[1], device="cuda", dtype=torch.bfloat16)
+    xp[:, :K] = torch.randn(M, K, device="cuda").bfloat16()
+    bias = torch.randn(N, device="cuda")
+    Np = L.cpad(N)
+    res = torch.randn(M, Np, device="cuda").bfloat16()
+    for kw in (dict(), dict(bias=bias, act=H.ACT_GELU), dict(bias=bias, residual=res, dropout=(0.1, 1234))):
+        def lin():
+            pre = L.empty((M, Np), torch.bfloat16, xp) if "act" in kw else None
+            y = L.linear_fwd(xp, M, wfl, N, pre=pre, **kw)
+            return y.clone(), (pre.clone() if pre is not None else None)
+        (a0, q0), (a1, q1) = both(lin)
+        Ns = (N + 7) // 8 * 8          # (the kernels store whole 8-column chunks; the pad columns beyond are never written)
+        assert torch.equal(a0[:, :Ns], a1[:, :Ns]) and (q0 is None or torch.equal(q0[:, :Ns], q1[:, :Ns])), sorted(kw)

@@ -69,7 +69,10 @@ def _assert_full_depth_gradients(g, stats, trunk_rel_bound=None, stem_ratio=(0.9
             lo, hi = min(lo, r16 - 0.1), max(hi, r16 + 0.1)
         assert lo <= st["ratio"] <= hi, (key, st)
         yard = st["cos16"]
-        floor = yard - 0.05 if yard == yard and yard > 0 else (0.55 if trunk else 0.97)    # (layer4: the yardstick run keeps no fp32 copy)
+        # (the stem of the conditioned model, whose 300 training steps are not reproducible, has been seen at 0.844 against a
+        # yardstick of 0.838 and at 0.874 against 0.925 in two runs of one afternoon: its margin is 0.10)
+        margin = 0.10 if key.endswith(".stem") else 0.05
+        floor = yard - margin if yard == yard and yard > 0 else (0.55 if trunk else 0.97)    # (layer4: the yardstick run keeps no fp32 copy)
         assert st["cos"] >= floor, (key, st, floor)
         if not trunk:
             assert st["cos"] >= 0.97, (key, st)
