@@ -281,7 +281,7 @@ def _report(batch, frames, size, samples, version, bwd, autocast, blocks, thread
     return res
 
 
-def conditioned_report(steps=300, batch=8, frames=16, size=112, samples=36800, lr=2e-4, pool=6, log=print, threads=16):
+def conditioned_report(steps=300, batch=8, frames=16, size=112, samples=36800, lr=2e-4, pool=6, log=print, threads=16, common_weight=1.0):
     """Full-depth parity for a CONDITIONED model: the HIP model is trained `steps` optimizer steps
     (BertAdam) on structured synthetic clips, `pool` batches in rotation; its state -- weights AND BatchNorm running
     statistics -- is loaded into the oracle, and the free-running stage errors, the embeddings and the full-depth
@@ -300,7 +300,9 @@ def conditioned_report(steps=300, batch=8, frames=16, size=112, samples=36800, l
     batches = [synthetic_structured_batch(batch, frames, size, samples, seed=100 + k).to("cuda") for k in range(pool)]
     g = torch.Generator().manual_seed(7)
     common = torch.randn(1, 1, 512, generator=g)
-    targets = F.normalize(common + torch.randn(pool, batch, 512, generator=g), dim=-1).cuda()
+    # (common_weight 1.0: pairwise cosine ~0.5 between the clips' targets; smaller: more spread, so that the trained model's
+    # diagonal similarities exceed some off-diagonal ones by more than the margin and the triplet loss's hinges are PARTLY active)
+    targets = F.normalize(common_weight * common + torch.randn(pool, batch, 512, generator=g), dim=-1).cuda()
     optim = pig.optimization.BertAdam(net.parameters(), lr=lr, warmup=0.05, t_total=2 * steps)
     t0, trace = time.time(), []
     for i in range(steps):

@@ -16,9 +16,10 @@ What bf16 activations cost, measured here with torch's own bf16 autocast of the 
     assertion is on quantities a wrong gradient cannot meet: per stage the NORM ratio against the fp32 oracle within
     0.9-1.1 and the COSINE not below the yardstick's (0.46-0.53) minus 0.05; the well-conditioned parts (audio tower,
     projection) are asserted tightly;
-  * the same for a CONDITIONED model (300 optimizer steps on structured clips, state loaded into the oracle): the
-    full-depth error leaves the ~1.0 regime (0.07-0.60) and is asserted against torch's own bf16 run (<= 1.15 x + 0.02), by norm
-    ratio and cosine, and with absolute bounds 1.4x above the larger of two measured runs (the training is not reproducible);
+  * the same for a CONDITIONED model (300 optimizer steps on structured clips towards nearly orthogonal targets, state
+    loaded into the oracle): the full-depth error leaves the ~1.0 regime (0.02-0.20) and is asserted against torch's own bf16
+    run (<= 1.15 x + 0.02), by norm ratio 0.9-1.1 and cosine, and with absolute bounds 1.4x above the largest of four measured
+    runs (the training is not reproducible);
   * configs[1] at its true batch 64 (forward + loss) and configs[2] (frozen wav2vec2) at the real geometry.
 """
 import pytest
@@ -61,18 +62,9 @@ def _assert_full_depth_gradients(g, stats, trunk_rel_bound=None, stem_ratio=(0.9
     for key, st in stats.items():
         trunk = key.startswith("video_encoder.video.")
         lo, hi = stem_ratio if key.endswith(".stem") else (0.9, 1.1)
-        # (where torch's own bf16 autocast of the SAME model state leaves that interval, the model state is what is badly
-        # conditioned: then within 0.1 of the yardstick's ratio.  Seen once: a 300-step trajectory whose stem gradient sits at
-        # 1.19 under torch bf16 and 1.24 here; the trajectory changes whenever a kernel's fp32 summation order does)
-        r16 = st.get("ratio16", float("nan"))
-        if r16 == r16:
-            lo, hi = min(lo, r16 - 0.1), max(hi, r16 + 0.1)
         assert lo <= st["ratio"] <= hi, (key, st)
         yard = st["cos16"]
-        # (the stem of the conditioned model, whose 300 training steps are not reproducible, has been seen at 0.844 against a
-        # yardstick of 0.838 and at 0.874 against 0.925 in two runs of one afternoon: its margin is 0.10)
-        margin = 0.10 if key.endswith(".stem") else 0.05
-        floor = yard - margin if yard == yard and yard > 0 else (0.55 if trunk else 0.97)    # (layer4: the yardstick run keeps no fp32 copy)
+        floor = yard - 0.05 if yard == yard and yard > 0 else (0.55 if trunk else 0.97)    # (layer4: the yardstick run keeps no fp32 copy)
         assert st["cos"] >= floor, (key, st, floor)
         if not trunk:
             assert st["cos"] >= 0.97, (key, st)
@@ -94,23 +86,29 @@ def test_gradients_under_a_smooth_objective(rep):
 
 def test_full_depth_gradients_of_a_conditioned_model():
     """the HIP model is trained 300 optimizer steps on structured clips, its state is loaded into the
-    oracle and the full-depth comparison is repeated.  Measured (r03, two runs: gpurun_out/r3/par_cond2.log, t1.log; the
-    training itself is not bitwise reproducible, so the trained states differ): the trunk's relative L2 error leaves the
-    ~1.0 regime of random init -- stem 0.49 / 0.60, layer1 0.52 / 0.54, layer2 0.45, layer3 0.27, layer4 0.07, the
-    torch-bf16 yardstick 0.47-0.63 / 0.52-0.55 / 0.45 / 0.27 -- with norm ratios 0.98-1.02 (stem, two conv tensors: 0.87-0.98,
-    the yardstick's 0.94-1.02) and cosines 0.80-0.998; the free-running activations stay within 3.7 % at every stage (25 % at
-    random init).  Asserted against the yardstick, by norm ratio and cosine, and with an absolute bound 1.4x above the larger of
-    the two measurements: the stem's error is the most sensitive to where the 300 unreproducible steps end (one run in six of
-    a later session measured 0.75 against a bound that was then 0.72)."""
+    oracle and the full-depth comparison is repeated.
+
+    Round 4: the clips' targets are nearly ORTHOGONAL (common_weight 0.3: pairwise cosine 0.08; rounds 2-3 used 0.5).  The
+    video tower then has to separate the clips (it reaches cosine 1.00 to every target) and ends in a state whose backward
+    pass is well conditioned in bf16: over four runs (tools/probe/cond_spread.py, profiles/r04_probe_cond_spread.log) the
+    trunk's relative L2 error against the fp32 oracle is stem 0.14-0.20, layer1 0.18-0.21, layer2 0.15-0.18, layer3
+    0.07-0.09, layer4 0.022 -- within 0.01 of the torch-bf16 yardstick's every time -- with norm ratios 0.97-1.01 and cosines
+    0.977-0.9998.  With the old targets the stem sat at the edge of its bounds (ratio 0.87 ... 1.24, cosine 0.84-0.87, error
+    0.49-0.75), which had them widened twice after failing runs; they are back to 0.9-1.1 and
+    yardstick - 0.05, the absolute bounds are 1.4x the largest of the four measurements.  (The training is not bitwise
+    reproducible -- fp32 atomics -- so every run ends in a slightly different state.  The AUDIO tower does not separate the
+    clips in 300 steps, whatever the learning rate: its embeddings stay on one point, every hinge of the triplet loss stays
+    active and the loss is 2 m (N-1)/N = 0.35 exactly, so the hinge-loss comparison below still does not run:
+    tools/probe/cond_dbg.py.)"""
     from parity_c2_report import conditioned_report
-    out = conditioned_report(steps=300)
+    out = conditioned_report(steps=300, common_weight=0.3)
     assert out["target_cosine"][-1] >= 0.6, out["target_cosine"]        # it did train
     rep = out["smooth"]
     assert rep["video_cos"] >= 0.9995 and rep["audio_cos"] >= 0.9995 and rep["dloss"] <= 1e-3
     for stage, (ours, yard) in rep["stages"].items():
-        assert ours <= 1.05 * yard + 1e-3 and ours <= 0.06, (stage, ours, yard)
-    bound = {"stem": 0.85, "layer1": 0.76, "layer2": 0.63, "layer3": 0.38, "layer4": 0.12}
-    _assert_full_depth_gradients(rep["grads"], rep["gstats"], trunk_rel_bound=bound, stem_ratio=(0.8, 1.2))
+        assert ours <= 1.05 * yard + 1e-3 and ours <= 0.03, (stage, ours, yard)
+    bound = {"stem": 0.28, "layer1": 0.30, "layer2": 0.26, "layer3": 0.13, "layer4": 0.035}
+    _assert_full_depth_gradients(rep["grads"], rep["gstats"], trunk_rel_bound=bound)
     assert rep["grads"]["audio"][0] <= 0.01 and rep["grads"]["video_encoder.project"][0] <= 0.02
     if "hinge" in out:      # the triplet loss's own gradient, when its hinges are neither all off nor all on
         _assert_full_depth_gradients(out["hinge"]["grads"], out["hinge"]["gstats"])
