@@ -281,7 +281,8 @@ def _report(batch, frames, size, samples, version, bwd, autocast, blocks, thread
     return res
 
 
-def conditioned_report(steps=300, batch=8, frames=16, size=112, samples=36800, lr=2e-4, pool=6, log=print, threads=16, common_weight=1.0):
+def conditioned_report(steps=300, batch=8, frames=16, size=112, samples=36800, lr=2e-4, pool=6, log=print, threads=16, common_weight=1.0,
+                       margin=None):
     """Full-depth parity for a CONDITIONED model: the HIP model is trained `steps` optimizer steps
     (BertAdam) on structured synthetic clips, `pool` batches in rotation; its state -- weights AND BatchNorm running
     statistics -- is loaded into the oracle, and the free-running stage errors, the embeddings and the full-depth
@@ -296,6 +297,8 @@ def conditioned_report(steps=300, batch=8, frames=16, size=112, samples=36800, l
     import pig.optimization
     torch.set_num_threads(threads)
     cfg = make_cfg()
+    if margin is not None:      # (the triplet loss's margin: only the hinge comparison at the end sees it)
+        cfg["margin"] = margin
     ref, net = build_pair(cfg)
     batches = [synthetic_structured_batch(batch, frames, size, samples, seed=100 + k).to("cuda") for k in range(pool)]
     g = torch.Generator().manual_seed(7)

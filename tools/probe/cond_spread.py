@@ -6,7 +6,8 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 from parity_c2_report import conditioned_report
 cw = float(sys.argv[1]) if len(sys.argv) > 1 else 0.3
-out = conditioned_report(steps=300, common_weight=cw)
+margin = float(sys.argv[2]) if len(sys.argv) > 2 else None
+out = conditioned_report(steps=300, common_weight=cw, margin=margin)
 print("target_cosine", out["target_cosine"], "hinge_active", out["hinge_active"], "hinge compared:", "hinge" in out)
 for key in ("smooth", "hinge"):
     if key in out:
