@@ -189,6 +189,9 @@ int pp_wgrad_xbn_supported(const pp_wgrad_desc* d);
  * transpose_io=1 builds the dgrad operand [Ci][taps(flipped)][cog]. */
 int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, void* out, int rows_out, int cg,
                         int transpose_io, int flip, float scale, pp_stream_t s);
+/* n contiguous fp32 copies in one launch (the gradient buckets' packing).  Item = 4 x int64 {src, dst, n floats, blk0}: one
+ * block copies 4096 consecutive floats, item i owns blocks [blk0_i, blk0_(i+1)), total_blocks = their sum */
+int pp_copy_f32_multi(const void* items, int n, long long total_blocks, pp_stream_t s);
 /* pp_prep_conv_weight for a DEVICE table of n weights in one launch (a tower's convolutions, both layouts).  Item = 88 bytes:
  * 10 x int64 {w (const float*), out, Co, Ci, taps, rows_out, cg, transpose_io, flip, blk0}, float scale, 4 bytes of padding.
  * One block converts 2048 consecutive elements of one `out`: item i owns blocks [blk0_i, blk0_(i+1)), blk0 ascending from 0,

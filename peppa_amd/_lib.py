@@ -82,6 +82,7 @@ SIGNATURES = {
     "pp_cast_pad_2d": [P, I, I, I, P, I, I, I, I, P],
     "pp_cast_pad_2d_multi": [P, I, I, P],
     "pp_prep_conv_weight_multi": [P, I, L, P],
+    "pp_copy_f32_multi": [P, I, L, P],
     "pp_cast_f32_to_bf16": [P, P, L, P],
     "pp_cast_bf16_to_f32": [P, P, L, P],
     "pp_copy_2d_f32": [P, I, P, I, I, I, P],

@@ -354,6 +354,41 @@ extern "C" int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, voi
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
+// many contiguous fp32 copies in one launch (gradient buckets: one per bucket instead of one hipMemcpyAsync per tensor)
+struct CopyItem { const float* src; float* dst; long long n, blk0; };
+__global__ __launch_bounds__(256) void copy_f32_multi_kernel(const CopyItem* __restrict__ items, const int n) {
+  int lo = 0, hi = n - 1;                       // last item whose first block is <= blockIdx.x (uniform: scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].blk0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CopyItem it = items[lo];
+  const long long base = ((long long)blockIdx.x - it.blk0) * 4096;
+  if ((((uintptr_t)it.src | (uintptr_t)it.dst) & 15) == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = base + (u * 256 + threadIdx.x) * 4;
+      if (i + 3 < it.n) {
+        *(float4*)(it.dst + i) = *(const float4*)(it.src + i);
+      } else {
+        for (long long j = i; j < it.n; ++j) it.dst[j] = it.src[j];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const long long i = base + u * 256 + threadIdx.x;
+      if (i < it.n) it.dst[i] = it.src[i];
+    }
+  }
+}
+extern "C" int pp_copy_f32_multi(const void* items, int n, long long total_blocks, pp_stream_t s) {
+  PP_CHECK_ARG(items && n > 0 && total_blocks > 0 && total_blocks < 0x7fffffffLL, "pp_copy_f32_multi: bad arguments");
+  static_assert(sizeof(CopyItem) == 32, "pp_copy_item layout (4 x 8 bytes)");
+  hipLaunchKernelGGL(copy_f32_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, S_, (const CopyItem*)items, n);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
 extern "C" int pp_prep_conv_weight_multi(const void* items, int n, long long total_blocks, pp_stream_t s) {
   PP_CHECK_ARG(items && n > 0 && total_blocks > 0 && total_blocks < 0x7fffffffLL, "pp_prep_conv_weight_multi: bad arguments");
   // (every `out` has fewer than 2^31 elements and is 16-byte aligned: the caller's table, peppa_amd/hip.py checks both)

@@ -61,8 +61,11 @@ class _PushDict(dict):
         self._mgr = mgr
 
     def __setitem__(self, k, v):
-        super().__setitem__(k, v)
-        self._mgr.push(k, v)
+        # a gradient the bucket manager TOOK is not handed to autograd as well: the tower returns None for it.  (Returned too,
+        # it has two owners, so autograd cannot adopt the tensor and clones it into p.grad -- one hipMemcpyAsync per
+        # parameter, 340 per step = 1.4 ms on the towers' streams -- only for finish() to replace p.grad by the bucket view.)
+        if not self._mgr.push(k, v):
+            super().__setitem__(k, v)
 
 
 def grad_dict():
@@ -142,26 +145,26 @@ class GradBuckets:
             b["accumulated"] = set()
 
     def push(self, p, g):
-        """Gradient `g` of parameter `p` is final for this backward pass (called on the stream that produces it).
-        `p.grad`, if it exists, holds the earlier micro-batches only: autograd adds `g` to it after the tower's node
-        returns (the hook then marks the parameter as accumulated)."""
+        """Gradient `g` of parameter `p` is final for this backward pass (called on the stream that produces it).  True: the
+        manager took it -- the caller must not return it to autograd as well; `p.grad`, if it exists, holds the earlier
+        micro-batches only and is added when the bucket is packed."""
         b = self._by_param.get(p)
         if not self.sync or b is None or g is None or p in b["pushed"] or b["work"] is not None:
-            return   # unsynced micro-batch / not ours / already handed over: autograd's accumulation takes it
+            return False   # unsynced micro-batch / not ours / already handed over: autograd's accumulation takes it
         b["pushed"][p] = g
         if self.cuda:
             b["events"][torch.cuda.current_stream()] = True   # (the set of producing streams)
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
+        return True
 
     def _on_grad(self, p):
         if not self.sync or p.grad is None:   # autograd also runs the hook when a Function returned None for this
             return                            # parameter (e.g. a layer skipped by LayerDrop): nothing arrived
         b = self._by_param[p]
         if p in b["pushed"]:
-            b["accumulated"].add(p)   # handed over early by its tower; p.grad now contains that gradient as well
-            return
+            return                    # handed over early by its tower (which returned None for it: p.grad is untouched)
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -188,7 +191,13 @@ class GradBuckets:
             else:
                 zero.append(v)
         if cp_dst:
-            torch._foreach_copy_(cp_dst, cp_src)          # plumbing: pack
+            # pack: one launch per bucket (torch._foreach_copy_ issues one hipMemcpyAsync per tensor on this stack: ~380 copies
+            # of 4 us per step, 1.6 ms on the towers' streams -- profiles/r04_probe_dist_overhead.log)
+            if self.cuda and all(s_.is_cuda and s_.dtype == torch.float32 and s_.is_contiguous() for s_ in cp_src):
+                from . import hip as H
+                H.copy_f32_multi(cp_dst, cp_src)
+            else:
+                torch._foreach_copy_(cp_dst, cp_src)
         if add_dst:
             torch._foreach_add_(add_dst, add_src)
         if zero:

@@ -316,6 +316,31 @@ def prep_conv_weight_multi(jobs, device):
     return tab, host
 
 
+_COPY_TABLES = {}      # (tuple of (src, dst, n)) -> (device table, pinned source, blocks): gradient tensors mostly keep their addresses
+
+
+def copy_f32_multi(dsts, srcs):
+    """dst_i <- src_i for contiguous fp32 tensors of equal sizes, ONE launch (pp_copy_f32_multi) instead of one copy each."""
+    key, blk0 = [], 0
+    for d, s_ in zip(dsts, srcs):
+        if d.dtype != f32 or s_.dtype != f32 or d.numel() != s_.numel() or not (d.is_contiguous() and s_.is_contiguous()):
+            raise PeppaHipError("copy_f32_multi: contiguous fp32 tensors of equal sizes")
+        key.append((s_.data_ptr(), d.data_ptr(), d.numel()))
+    key = tuple(key)
+    hit = _COPY_TABLES.get(key)
+    if hit is None:
+        rows = []
+        for (sp, dp, n) in key:
+            rows.append([sp, dp, n, blk0])
+            blk0 += (n + 4095) // 4096
+        host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        tab = host.to(dsts[0].device, non_blocking=True)
+        if len(_COPY_TABLES) > 256:
+            _COPY_TABLES.clear()
+        hit = _COPY_TABLES[key] = (tab, host, blk0)
+    call("pp_copy_f32_multi", C.c_void_p(hit[0].data_ptr()), len(key), hit[2], _s())
+
+
 def copy_2d_f32(inp, ld_in, out, ld_out, rows, cols):
     call("pp_copy_2d_f32", _p(inp, f32), ld_in, _p(out, f32), ld_out, rows, cols, _s())
 
