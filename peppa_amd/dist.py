@@ -105,7 +105,7 @@ class GradBuckets:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             self.buckets.append(dict(name=name, params=params, flat=flat, views=views, pending=0, work=None,
-                                     pushed={}, events={}, accumulated=set()))
+                                     pushed={}, events={}))
         self._hooks = []
         self._by_param = {}
         for b in self.buckets:
@@ -142,7 +142,6 @@ class GradBuckets:
             b["work"] = None
             b["pushed"] = {}
             b["events"] = {}
-            b["accumulated"] = set()
 
     def push(self, p, g):
         """Gradient `g` of parameter `p` is final for this backward pass (called on the stream that produces it).  True: the
@@ -171,13 +170,14 @@ class GradBuckets:
 
     def _pack(self, b):
         """flat view <- this optimizer step's gradient of every parameter: the early hand-off plus what earlier
-        micro-batches left in p.grad, or p.grad itself once autograd has accumulated into it; zeros for none."""
+        micro-batches left in p.grad (a gradient handed over early is never given to autograd as well), or p.grad itself for
+        the parameters that arrived through autograd; zeros for none."""
         cp_dst, cp_src, add_dst, add_src, zero = [], [], [], [], []
         for p, v in zip(b["params"], b["views"]):
             g = b["pushed"].get(p)
             # (p.grad can BE the view: zero_grad(set_to_none=False) keeps last step's tensor and accumulates into it)
             alias = p.grad is not None and p.grad.data_ptr() == v.data_ptr()
-            if g is not None and p not in b["accumulated"]:
+            if g is not None:
                 if alias:
                     add_dst.append(v), add_src.append(g)
                     continue
