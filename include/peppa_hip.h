@@ -189,6 +189,14 @@ int pp_wgrad_xbn_supported(const pp_wgrad_desc* d);
  * transpose_io=1 builds the dgrad operand [Ci][taps(flipped)][cog]. */
 int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, void* out, int rows_out, int cg,
                         int transpose_io, int flip, float scale, pp_stream_t s);
+/* The paired-pixel stem convolution (Conv3d(3, Co <= 48, (1,7,7), stride (1,2,2), padding (0,3,3)) over the input
+ * pp_video_normalize_ndhwc4 writes and the weights pp_prep_conv_weight_pairs lays out) as a window kernel: x [images][Hi][Wp
+ * pairs][8] bf16, wf [Co][7 x 4 taps][8], y [images * Ho * Wp][ldc] bf16 with Ho = (Hi - 1) / 2 + 1; Wp <= 64.  colstats (or
+ * NULL): [pp_stem_pairs_stat_rows(images, Hi)][2][ldstat] fp32 partial column sums / sums of squares, one row per (image, four
+ * output rows).  Same bits in y as pp_igemm on the same operands (same K order).  torchvision stem[0], pig/models.py:141-150 */
+long long pp_stem_pairs_stat_rows(int images, int Hi);
+int pp_stem_pairs_fwd(const void* x, const void* wf, void* y, float* colstats, int images, int Hi, int Wp, int Co, int ldc,
+                      int ldstat, pp_stream_t s);
 /* n contiguous fp32 copies in one launch (the gradient buckets' packing).  Item = 4 x int64 {src, dst, n floats, blk0}: one
  * block copies 4096 consecutive floats, item i owns blocks [blk0_i, blk0_(i+1)), total_blocks = their sum */
 int pp_copy_f32_multi(const void* items, int n, long long total_blocks, pp_stream_t s);

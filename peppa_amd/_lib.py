@@ -83,6 +83,8 @@ SIGNATURES = {
     "pp_cast_pad_2d_multi": [P, I, I, P],
     "pp_prep_conv_weight_multi": [P, I, L, P],
     "pp_copy_f32_multi": [P, I, L, P],
+    "pp_stem_pairs_fwd": [P, P, P, P, I, I, I, I, I, I, P],
+    "pp_stem_pairs_stat_rows": [I, I],
     "pp_cast_f32_to_bf16": [P, P, L, P],
     "pp_cast_bf16_to_f32": [P, P, L, P],
     "pp_copy_2d_f32": [P, I, P, I, I, I, P],
@@ -144,7 +146,7 @@ SIGNATURES = {
     "pp_triplet_accuracy": [P, P, P, I, I, I, P, P],
     "pp_bertadam_step": [C.POINTER(TensorList), P, P, I, I, P, F, F, F, F, F, F, P, P, P],
 }
-_RESTYPE = {"pp_igemm_stat_rows": L, "pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z, "pp_wgrad_ws_floats": L}
+_RESTYPE = {"pp_igemm_stat_rows": L, "pp_stem_pairs_stat_rows": L, "pp_last_error": C.c_char_p, "pp_attnpool_ws_floats": Z, "pp_triplet_workspace_bytes": Z, "pp_wgrad_ws_floats": L}
 _NO_STATUS = set(_RESTYPE) | {"pp_version", "pp_dtype", "pp_experimental_build"}
 
 _libs = {}

@@ -363,6 +363,15 @@ def video_normalize_ndhwc(x, out, mean3, std3):
          B, T, H, W, m, sd, _s())
 
 
+def stem_pairs_stat_rows(images, Hi):
+    return int(_lib.lib().pp_stem_pairs_stat_rows(images, Hi))
+
+
+def stem_pairs_fwd(x, wf, y, colstats, images, Hi, Wp, Co, ldc, ldstat):
+    """The paired-pixel stem convolution as a window kernel (pp_stem_pairs_fwd)."""
+    call("pp_stem_pairs_fwd", _p(x, act16()), _p(wf, act16()), _p(y, act16()), _p(colstats, f32), images, Hi, Wp, Co, ldc, ldstat, _s())
+
+
 def prep_conv_weight_pairs(w, out, Co, Ci, kth, kw, pw):
     call("pp_prep_conv_weight_pairs", _p(w, f32), Co, Ci, kth, kw, pw, _p(out, act16()), _s())
 

@@ -270,10 +270,27 @@ def can_fuse_bn_apply(geom):
             H.wgrad_xbn_supported(geom.M, geom.Co, geom.Kf, geom.g_fwd(), geom.out_cstride))
 
 
+STEM_WINDOW = True        # A/B switch (tools/ab_step.py stem_window): pp_stem_pairs_fwd for the paired-pixel stem
+
+
+def _stem_window_ok(geom):
+    """The (1,7,7) stride-(1,2,2) padding-(0,3,3) stem over pixel pairs, frames up to 64 pairs (128 pixels) wide, <= 48 output
+    channels (r2plus1d_18's 45): what pp_stem_pairs_fwd is built for."""
+    return (geom.pairs is not None and geom.groups == 1 and geom.pairs[1] == 7 and geom.pairs[2] == 3 and geom.k == (1, 7, 4) and
+            geom.s == (1, 2, 1) and geom.p[:2] == (0, 3) and geom.Wi <= 64 and geom.Wo == geom.Wi and geom.Co <= 48 and
+            geom.in_cstride == 8 and geom.To == geom.Ti)
+
+
 def conv_fwd(x, geom, wf, *, stats=False, bias=None, act=H.ACT_NONE, out=None, pre=None, x_bn=None):
     """y[M][out_cstride] = conv(x); optional per-column partial sums for BatchNorm.
     x_bn = (scale, shift, relu): x is the raw output of a BatchNorm unit whose apply pass was skipped (can_fuse_bn_apply)."""
     y = out if out is not None else empty((geom.M, geom.out_cstride), act16(), x)
+    if STEM_WINDOW and _stem_window_ok(geom) and bias is None and act == H.ACT_NONE and pre is None and x_bn is None:
+        # the paired-pixel stem as a window kernel: the input is read once instead of 28 x 16 bytes per output row
+        images = geom.B * geom.Ti
+        partials = empty((H.stem_pairs_stat_rows(images, geom.Hi), 2, geom.out_cstride), f32, x) if stats else None
+        H.stem_pairs_fwd(x, wf, y, partials, images, geom.Hi, geom.Wi, geom.Co, geom.out_cstride, geom.out_cstride)
+        return y, partials
     # (rows of partial statistics: one per 128 output rows, a few more where the temporal window kernel's tiles do not
     # divide the clip evenly -- callers pass partials.shape[0] on to bn_fwd, not geom.nblk)
     partials = None

@@ -1685,3 +1685,36 @@ def test_wide_tile_forward_and_data_gradient_are_bit_identical_to_the_default_ke
         (a0, q0), (a1, q1) = both(lin)
         Ns = (N + 7) // 8 * 8          # (the kernels store whole 8-column chunks; the pad columns beyond are never written)
         assert torch.equal(a0[:, :Ns], a1[:, :Ns]) and (q0 is None or torch.equal(q0[:, :Ns], q1[:, :Ns])), sorted(kw)
+
+
+@pytest.mark.parametrize("B,T,Hh,W,Co", [(2, 3, 112, 112, 45), (1, 2, 64, 64, 45), (3, 1, 30, 50, 45), (2, 2, 112, 112, 48), (1, 1, 14, 128, 33)])
+def test_stem_window_kernel_matches_the_gather_kernel_and_conv3d(B, T, Hh, W, Co):
+    """pp_stem_pairs_fwd (round 4: the paired-pixel stem as a window kernel, the input read once): the same bits in y as
+    pp_igemm's gather kernel on the same operands (same K order), column statistics equal to fp32 rounding (other partial
+    rows), and y against torch's Conv3d in fp32; odd sizes (Ho not a multiple of 4, Wp not a multiple of 16, the widest
+    frame) and 48 / 33 output channels."""
+    torch.manual_seed(2)
+    geom = L.ConvGeom.paired_stem(B, (T, Hh, W), 3, Co, (1, 7, 7), (1, 2, 2), (0, 3, 3))
+    assert geom is not None and L._stem_window_ok(geom)
+    xv = torch.rand(B, 3, T, Hh, W, device="cuda")
+    x4 = torch.zeros(B, T, Hh, W, 4, device="cuda")
+    x4[..., :3] = xv.permute(0, 2, 3, 4, 1)
+    x = x4.bfloat16().view(-1, 8)
+    w = torch.randn(Co, 3, 1, 7, 7, device="cuda") * 0.05
+    wf, _ = L.prep_conv_weights(w, geom, need_dgrad=False)
+    prev = L.STEM_WINDOW
+    try:
+        L.STEM_WINDOW = False
+        y0, p0 = L.conv_fwd(x, geom, wf, stats=True)
+        L.STEM_WINDOW = True
+        y1, p1 = L.conv_fwd(x, geom, wf, stats=True)
+        y2, none = L.conv_fwd(x, geom, wf)
+    finally:
+        L.STEM_WINDOW = prev
+    nc = (Co + 7) // 8 * 8
+    assert torch.equal(y0[:, :nc], y1[:, :nc]) and torch.equal(y1[:, :nc], y2[:, :nc]) and none is None
+    s0, s1 = p0.double().sum(0)[:, :Co], p1.double().sum(0)[:, :Co]
+    assert (s0 - s1).abs().max().item() <= 1e-6 * s0.abs().max().item()
+    ref = F.conv3d(xv.bfloat16().float(), w.bfloat16().float(), stride=(1, 2, 2), padding=(0, 3, 3))      # (B, Co, T, Ho, Wo)
+    got = y1[:, :Co].float().view(B, T, geom.Ho, geom.Wo, Co).permute(0, 4, 1, 2, 3)
+    assert (got - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-3

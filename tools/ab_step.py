@@ -91,6 +91,8 @@ def set_switch(name, on):
         H.set_option("win_tall", 0 if on else 1)
         H.set_option("win_partial", 1 if on else 0)
         H.set_option("win_kpb", 2 if on else 1)
+    elif name == "stem_window":     # the paired-pixel stem's forward as a window kernel
+        L.STEM_WINDOW = bool(on)
     elif name == "igemm_big":       # 256 x 256 forward / data-gradient tiles (plain epilogues)
         from peppa_amd import hip as H
         H.set_option("igemm_big", 8192 if on else 0)
@@ -109,7 +111,7 @@ def set_switch(name, on):
         raise SystemExit(f"unknown switch {name}")
 
 
-defaults = {"r4_all": True, "prep_plan": True, "wgrad_big": True, "igemm_big": False, "win_tall": False, "win_s2d": True, "wgrad_flat": True, "win_producers_all": True, "ring_producers": True, "win_producers_tw": True, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
+defaults = {"r4_all": True, "prep_plan": True, "wgrad_big": True, "igemm_big": False, "stem_window": True, "win_tall": False, "win_s2d": True, "wgrad_flat": True, "win_producers_all": True, "ring_producers": True, "win_producers_tw": True, "win_producers": True, "tw_producers": True, "tw_narrow": True, "group_wgrad": True, "win_stagger": False, "paired_stem": True, "fuse_bn_apply": True, "persist_cus248": False, "persist_cus240": False, "persist_cus224": False, "fuse_bnr": False, "wgrad_side": False, "bn_tuned": True, "out_nt": True}
 for _ in range(3):
     step(0)
 for name in sys.argv[1:]:
