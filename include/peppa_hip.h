@@ -197,6 +197,9 @@ int pp_prep_conv_weight(const float* w, int Co, int Ci, int taps, void* out, int
 long long pp_stem_pairs_stat_rows(int images, int Hi);
 int pp_stem_pairs_fwd(const void* x, const void* wf, void* y, float* colstats, int images, int Hi, int Wp, int Co, int ldc,
                       int ldstat, pp_stream_t s);
+/* its weight gradient on the same window: dw [Co][7 x 4 taps][8] fp32 (pp_unprep_conv_grad_pairs' input) += sum over the
+ * output positions; the caller zeroes dw; dy [images * Ho * Wp][ldy] bf16.  fp32 atomics across workgroups */
+int pp_stem_pairs_wgrad(const void* x, const void* dy, float* dw, int images, int Hi, int Wp, int Co, int ldy, pp_stream_t s);
 /* n contiguous fp32 copies in one launch (the gradient buckets' packing).  Item = 4 x int64 {src, dst, n floats, blk0}: one
  * block copies 4096 consecutive floats, item i owns blocks [blk0_i, blk0_(i+1)), total_blocks = their sum */
 int pp_copy_f32_multi(const void* items, int n, long long total_blocks, pp_stream_t s);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "pp_copy_f32_multi": [P, I, L, P],
     "pp_stem_pairs_fwd": [P, P, P, P, I, I, I, I, I, I, P],
     "pp_stem_pairs_stat_rows": [I, I],
+    "pp_stem_pairs_wgrad": [P, P, P, I, I, I, I, I, P],
     "pp_cast_f32_to_bf16": [P, P, L, P],
     "pp_cast_bf16_to_f32": [P, P, L, P],
     "pp_copy_2d_f32": [P, I, P, I, I, I, P],

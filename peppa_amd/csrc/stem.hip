@@ -140,6 +140,94 @@ __global__ __launch_bounds__(256, 2) void stem_pairs_fwd_kernel(const h16raw* __
   }
 }
 
+
+// ---- weight gradient on the same window ---------------------------------------------------------------------------------------
+// dW[co][tap * 8 + c] = sum over output positions m of dY[m][co] * X[m's window at tap][c].  The reduce index of the MFMA is m:
+// 32 consecutive output columns of one output row per k-block.  Both fragments are transposing LDS reads (ds_read_b64_tr_b16,
+// the same row -> k permutation on either side): dY^T from the tile's dY rows ([m][48 columns], 96-byte rows), X^T from the
+// window seen as a matrix of 16-byte rows (one pair) and 16 columns (two pair taps x 8 channels) starting at pair ow + dj.
+// A wave owns the kernel rows {wave, wave + 4} (x two halves of the four pair taps): 3 x 4 accumulator tiles; persistent
+// workgroups add their sums to dW once, at the end (fp32 atomics: not for the deterministic mode).
+constexpr int DYS = 96;          // dY tile row stride in bytes (48 columns): 32 x 3, conflict-free transposing reads
+
+__device__ __forceinline__ h16x8 tr_frag32(const unsigned char* tile, int stride, int lane) {
+  // rows {4g..4g+3} and {16+4g..16+4g+3} (g = lane >> 4) of 16 columns; lane (4q+p) supplies row q, columns 4p..4p+3
+  const int gq = lane >> 4, li = lane & 15;
+  const unsigned char* a0 = tile + (4 * gq + (li >> 2)) * stride + (li & 3) * 8;
+  const h16x4 lo = ds_read_tr16(a0);
+  const h16x4 hi = ds_read_tr16(a0 + 16 * stride);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 4) void stem_pairs_wgrad_kernel(const h16raw* __restrict__ x, const h16raw* __restrict__ dy,
+                                                                  float* __restrict__ dw, const int Hi, const int Wp, const int Ho,
+                                                                  const int Co, const int ldy, const int tiles_per_image,
+                                                                  const int ntiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char win[WROWS * WS * 16 + 64];
+  __shared__ __attribute__((aligned(16))) unsigned char dyt[4 * 64 * DYS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[NJ][4];           // [co tile][slot]: slot = (kernel row wave or wave + 4) x (pair taps {0,1} or {2,3})
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) acc[j][sl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool second = wave + 4 < KR;             // (wave 3 owns kernel row 3 only)
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int img = tile / tiles_per_image, oh0 = (tile % tiles_per_image) * 4;
+    if (tile != (int)blockIdx.x) __syncthreads();
+    for (int idx = tid; idx < WROWS * WS; idx += 256) {
+      const int r = idx / WS, c = idx - r * WS;
+      const int ih = 2 * oh0 - 3 + r, pw = c - 2;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((unsigned)ih < (unsigned)Hi && (unsigned)pw < (unsigned)Wp) v = *(const uint4*)(x + (((long long)img * Hi + ih) * Wp + pw) * 8);
+      *(uint4*)(win + idx * 16) = v;
+    }
+    // the tile's dY: 4 output rows x 64 positions (zeros past Wp / Ho) x 48 columns (6 chunks of 8)
+    for (int idx = tid; idx < 4 * 64 * 6; idx += 256) {
+      const int ch = idx % 6, m = idx / 6;
+      const int orow = m >> 6, ow = m & 63;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (oh0 + orow < Ho && ow < Wp && ch * 8 < ldy) v = *(const uint4*)(dy + (((long long)img * Ho + oh0 + orow) * Wp + ow) * ldy + ch * 8);
+      *(uint4*)(dyt + m * DYS + ch * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int orow = 0; orow < 4; ++orow) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        if (mb * 32 >= Wp) break;
+        h16x8 af[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) af[j] = tr_frag32(dyt + (orow * 64 + mb * 32) * DYS + j * 32, DYS, lane);
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          if (sl >= 2 && !second) break;
+          const int dh = wave + 4 * (sl >> 1), dj = 2 * (sl & 1);
+          const h16x8 bf = tr_frag32(win + ((2 * orow + dh) * WS + mb * 32 + dj) * 16, 16, lane);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[j][sl] = PP_MFMA16(af[j], bf, acc[j][sl], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // acc[j][sl][r] = dW[co = j * 16 + fq * 4 + r][k = (dh * 4 + dj) * 8 + fr]
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    if (sl >= 2 && !second) break;
+    const int dh = wave + 4 * (sl >> 1), dj = 2 * (sl & 1);
+    const int k = (dh * 4 + dj) * 8 + fr;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = j * 16 + fq * 4 + r;
+        if (co < Co) atomicAdd(dw + (long long)co * (KR * 4 * 8) + k, acc[j][sl][r]);
+      }
+  }
+}
+
 }  // namespace
 
 // rows of column statistics pp_stem_pairs_fwd writes: one per (image, 4 output rows)
@@ -159,6 +247,23 @@ extern "C" int pp_stem_pairs_fwd(const void* x, const void* wf, void* y, float* 
   const long long gx = ntiles < 256 * 2 ? ntiles : 256 * 2;       // two workgroups per CU (216 registers; three spill: 321 us against 150)
   hipLaunchKernelGGL(stem_pairs_fwd_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)s, (const h16raw*)x,
                      (const h16raw*)wf, (h16raw*)y, colstats, Hi, Wp, Ho, Co, ldc, ldstat, tiles, (int)ntiles);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+/* dw [Co][7 x 4 taps][8] fp32 += the stem's weight gradient (the caller zeroes dw); x, Hi, Wp, Co as pp_stem_pairs_fwd,
+ * dy [images * Ho * Wp][ldy] bf16.  fp32 atomics across workgroups: not bitwise reproducible. */
+extern "C" int pp_stem_pairs_wgrad(const void* x, const void* dy, float* dw, int images, int Hi, int Wp, int Co, int ldy,
+                                   pp_stream_t s) {
+  PP_CHECK_ARG(x && dy && dw && images > 0 && Hi >= 7 && Wp >= 4 && Wp <= 64 && Co > 0 && Co <= 48, "pp_stem_pairs_wgrad: sizes (Wp <= 64, Co <= 48)");
+  PP_CHECK_ARG(ldy % 8 == 0 && ldy >= ((Co + 7) & ~7), "pp_stem_pairs_wgrad: ldy");
+  const int Ho = (Hi + 2 * 3 - 7) / 2 + 1;
+  const int tiles = (Ho + 3) / 4;
+  const long long ntiles = (long long)images * tiles;
+  PP_CHECK_ARG(ntiles < 0x7fffffffLL && (long long)images * Hi * Wp * 8 < 0x7fffffffLL && (long long)images * Ho * Wp * ldy < 0x7fffffffLL, "pp_stem_pairs_wgrad: too large");
+  const long long gx = ntiles < 256 * 4 ? ntiles : 256 * 4;       // four workgroups per CU (90 registers, 39 KB of LDS): 2: 216, 3: 177, 4: 164 us
+  hipLaunchKernelGGL(stem_pairs_wgrad_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)s, (const h16raw*)x, (const h16raw*)dy,
+                     dw, Hi, Wp, Ho, Co, ldy, tiles, (int)ntiles);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

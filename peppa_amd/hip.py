@@ -372,6 +372,11 @@ def stem_pairs_fwd(x, wf, y, colstats, images, Hi, Wp, Co, ldc, ldstat):
     call("pp_stem_pairs_fwd", _p(x, act16()), _p(wf, act16()), _p(y, act16()), _p(colstats, f32), images, Hi, Wp, Co, ldc, ldstat, _s())
 
 
+def stem_pairs_wgrad(x, dy, dw, images, Hi, Wp, Co, ldy):
+    """dw fp32 [Co][28][8] += the paired-pixel stem's weight gradient (pp_stem_pairs_wgrad; dw zeroed by the caller)."""
+    call("pp_stem_pairs_wgrad", _p(x, act16()), _p(dy, act16()), _p(dw, f32), images, Hi, Wp, Co, ldy, _s())
+
+
 def prep_conv_weight_pairs(w, out, Co, Ci, kth, kw, pw):
     call("pp_prep_conv_weight_pairs", _p(w, f32), Co, Ci, kth, kw, pw, _p(out, act16()), _s())
 

@@ -393,6 +393,10 @@ def conv_dgrad(dy, geom, wd, *, residual=None, consumer=None):
 def conv_wgrad_raw(x, dy, geom, x_bn=None):
     """fp32 gradient in operand layout [Co][taps][cg_in]."""
     gw = zeros((geom.Co, geom.taps, geom.cg_in), f32, x)
+    if STEM_WINDOW and x_bn is None and not H.DETERMINISTIC and _stem_window_ok(geom):
+        # the paired-pixel stem on its window kernel (fp32 atomics across workgroups: the deterministic mode keeps pp_wgrad's slabs)
+        H.stem_pairs_wgrad(x, dy, gw, geom.B * geom.Ti, geom.Hi, geom.Wi, geom.Co, geom.out_cstride)
+        return gw
     if geom.groups == 1:
         H.wgrad(x, dy, gw, geom.M, geom.Co, geom.Kf, geom.g_fwd(), geom.out_cstride, geom.Kf, x_bn=x_bn)
     else:

@@ -1718,3 +1718,19 @@ def test_stem_window_kernel_matches_the_gather_kernel_and_conv3d(B, T, Hh, W, Co
     ref = F.conv3d(xv.bfloat16().float(), w.bfloat16().float(), stride=(1, 2, 2), padding=(0, 3, 3))      # (B, Co, T, Ho, Wo)
     got = y1[:, :Co].float().view(B, T, geom.Ho, geom.Wo, Co).permute(0, 4, 1, 2, 3)
     assert (got - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-3
+    # the weight gradient on the same window (pp_stem_pairs_wgrad): against the gather kernel (fp32 summation order) and torch
+    dy = torch.zeros(geom.M, geom.out_cstride, device="cuda", dtype=torch.bfloat16)
+    dy[:, :Co] = torch.randn(geom.M, Co, device="cuda").bfloat16()
+    try:
+        L.STEM_WINDOW = False
+        g0 = L.conv_wgrad(x, dy, geom, w.shape).clone()
+        L.STEM_WINDOW = True
+        g1 = L.conv_wgrad(x, dy, geom, w.shape).clone()
+    finally:
+        L.STEM_WINDOW = prev
+    assert (g1 - g0).abs().max().item() <= 2e-5 * g0.abs().max().item()
+    xr = xv.bfloat16().float().requires_grad_(False)
+    wr = w.clone().requires_grad_(True)
+    out = F.conv3d(xr, wr, stride=(1, 2, 2), padding=(0, 3, 3))
+    out.backward(dy[:, :Co].float().view(B, T, geom.Ho, geom.Wo, Co).permute(0, 4, 1, 2, 3).contiguous())
+    assert (g1 - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()
