@@ -9,6 +9,7 @@ import sys
 
 FAMILIES = [
     ("window conv fwd/dgrad (igemm_win)", r"igemm_win_kernel"),
+    ("stem window kernels (fwd + wgrad)", r"stem_pairs"),
     ("generic / ring implicit GEMM (igemm)", r"igemm_kernel"),
     ("sliding-window wgrad (wgrad_sw)", r"wgrad_sw_kernel"),
     ("temporal-window wgrad (wgrad_tw)", r"wgrad_tw_kernel"),
